@@ -1,0 +1,62 @@
+"""Build the HIP shared library in-tree for gfx950 (cross-compiles without a GPU).
+
+    python -m qwen3_tts_axera_russian_amd.build
+
+Outputs (git-ignored, shipped to the GPU box by gpurun):
+    lib/libqwen3tts.so     every C-ABI symbol of include/*.h
+    lib/llama_wrapper.so   the same file under the name the reference's
+                           llama_cpp_bindings.py:18-35 looks for
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib")
+SOURCES = ["q3_common.cpp", "q3_kernels.hip", "q3_model.hip", "q3_talker_api.hip", "q3_cp_api.hip",
+           "q3_engine.hip", "q3_voc.hip", "q3_test_api.hip"]
+ARCH = os.environ.get("Q3_OFFLOAD_ARCH", "gfx950")
+
+
+def _newer(dst: str, srcs) -> bool:
+    if not os.path.exists(dst):
+        return False
+    t = os.path.getmtime(dst)
+    return all(os.path.getmtime(s) <= t for s in srcs)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIB, exist_ok=True)
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs += [os.path.join(HERE, "..", "include", f) for f in os.listdir(os.path.join(HERE, "..", "include"))]
+    out = os.path.join(LIB, "libqwen3tts.so")
+    objs = []
+    for s in srcs:
+        o = os.path.join(LIB, os.path.basename(s) + ".o")
+        objs.append(o)
+        if not force and _newer(o, [s] + hdrs):
+            continue
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", s, "-o", o,
+               "-Wno-unused-result", "-Wno-unused-value", "-Wno-pass-failed"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    if force or not _newer(out, objs):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    alias = os.path.join(LIB, "llama_wrapper.so")
+    if not os.path.exists(alias) or os.path.getmtime(alias) < os.path.getmtime(out):
+        shutil.copyfile(out, alias)
+    return out
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

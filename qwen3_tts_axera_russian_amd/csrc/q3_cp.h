@@ -1,0 +1,21 @@
+// q3_cp.h -- one code-predictor frame over R rows (shared by the cp_* ABI and the fused engine).
+#pragma once
+#include "q3_model.h"
+
+namespace q3 {
+
+struct CpFrameIO {
+    int* codes = nullptr;           // device codes array (see TalkerSampleArgs); column 0 = code_0 is read
+    const int* n_frames = nullptr;  // device [R]
+    int frame_cap = 1;
+    // feedback after the last group (tts_client.py:199-208); null = none
+    float* fb_h = nullptr;
+    float* fb_ssq = nullptr;
+    const float* pad_embed = nullptr;
+};
+
+// w.h / w.ssq hold the talker hidden of each row (position 0 input).  Runs positions 0..n_groups,
+// writes columns 1..n_groups of each row's frame.
+int cp_frame(hipStream_t s, const Model& m, Work& w, KVCache& kv, int R, const CpFrameIO& io);
+
+}  // namespace q3

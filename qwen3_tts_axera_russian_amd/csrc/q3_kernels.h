@@ -1,0 +1,139 @@
+// q3_kernels.h -- launch interface of the gfx950 kernels (q3_kernels.hip).
+//
+// Numerics contract shared with oracle/q3_oracle.c (DESIGN.md "Numerics"):
+//   * projection weights fp16, residual stream / norms / softmax / tables f32,
+//     every GEMM input rounded to fp16 (saturating), f32 accumulation;
+//   * K/V cache fp16, q kept f32.
+#pragma once
+#include "q3_common.h"
+
+namespace q3 {
+
+enum { PRO_F16 = 0, PRO_NORM = 1 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2 };
+
+// y[M][N] = A[M][K] . W[N][K]^T with W in MFMA-fragment order (see pack_linear).
+struct LinArgs {
+    const half_t* wp = nullptr;  // packed weights
+    int N = 0, K = 0, M = 0;
+    int nt = 0;  // 1: stream the weights with non-temporal loads (read once per step: talker)
+    // prologue PRO_F16: A = x16[M][K] (fp16).  PRO_NORM: A = fp16((h*inv)*gamma),
+    // inv[m] = 1/sqrt(sum(ssq[m][0..ssq_parts))/K + eps).
+    const half_t* x16 = nullptr;
+    const float* h = nullptr;
+    const float* ssq = nullptr;
+    int ssq_parts = 0;
+    const float* gamma = nullptr;
+    float eps = 1e-6f;
+    // EPI_STORE: y[m*ldy + n] = acc
+    float* y = nullptr;
+    int ldy = 0;
+    // EPI_RESID: h_out[m*N+n] += acc; ssq_out[m*(N/16) + n/16] = sum of squares of the new 16 values
+    float* h_out = nullptr;
+    float* ssq_out = nullptr;
+    // EPI_SWIGLU (gate/up tile-interleaved weights): act[m*(N/2)+j] = fp16(silu(g)*u)
+    half_t* act = nullptr;
+};
+int launch_linear(hipStream_t s, const LinArgs& a, int pro, int epi);
+
+// Repack a row-major fp16 matrix src[N][K] into fragment order inside dst:
+// source 16-row tile ts lands at destination tile (tile_off + ts*tile_stride).
+int launch_pack_linear(hipStream_t s, const half_t* src, int N, int K, half_t* dst, int tile_off,
+                       int tile_stride);
+
+enum { ATTN_FUSED = 0, ATTN_PREP = 1, ATTN_ATTEND = 2 };
+struct AttnArgs {
+    float* qkv = nullptr;  // [R][ld]: q heads, then k heads, then v heads (raw projections)
+    int ld = 0, R = 0;
+    const float* q_norm = nullptr;
+    const float* k_norm = nullptr;
+    float eps = 1e-6f;
+    const float* rope_cos = nullptr;  // [max_pos][64]
+    const float* rope_sin = nullptr;
+    const int* slot = nullptr;  // [R] or null -> slot_base + r*slot_stride
+    const int* pos = nullptr;   // [R] or null -> pos_base + r*pos_stride
+    int slot_base = 0, slot_stride = 0, pos_base = 0, pos_stride = 0;
+    half_t* kc = nullptr;  // this layer: [slot][n_kv][n_ctx][128]
+    half_t* vc = nullptr;
+    int n_ctx = 0, n_kv = 0, n_heads = 0;
+    half_t* out = nullptr;  // [R][n_heads*128]
+    float scale = 0.f;
+    int threads = 256;
+};
+int launch_attn(hipStream_t s, const AttnArgs& a, int mode);
+
+// ssq[m][p] = sum_{k in 16-block p} h[m][k]^2  (H/16 partials per row)
+int launch_ssq_rows(hipStream_t s, const float* h, float* ssq, int R, int H);
+
+// hidden = (h*inv)*gamma per row; optional outputs: f32 hidden, fp16 hidden,
+// a second f32 copy (+ its ssq partials) that seeds the code predictor.
+struct FinalNormArgs {
+    const float* h = nullptr;
+    const float* ssq = nullptr;
+    int ssq_parts = 0;
+    const float* gamma = nullptr;
+    float eps = 1e-6f;
+    int R = 0, H = 0;
+    const int* row_map = nullptr;  // optional: source row of output row r
+    float* out_f32 = nullptr;
+    half_t* out_f16 = nullptr;
+    float* out_copy = nullptr;
+    float* out_copy_ssq = nullptr;
+};
+int launch_final_norm(hipStream_t s, const FinalNormArgs& a);
+
+// h[r] = table[tok_r] (zeros when tok_r is out of range), with ssq partials.  tok_r = tok[r*tok_stride]
+// when n_frames is null, else column `col` of row r's current frame in a codes array laid out as in
+// TalkerSampleArgs (frame = n_frames[r]-1, clamped to [0, frame_cap)).
+int launch_gather_embed(hipStream_t s, const float* table, int V, int H, const int* tok, int tok_stride,
+                        const int* n_frames, int frame_cap, int col, float* h, float* ssq, int R);
+
+// Talker sampling (llamacpp_talker_server.py:163-206, greedy form).
+struct TalkerSampleArgs {
+    const float* logits = nullptr;  // [R][V]
+    int V = 0, R = 0;
+    int audio_vocab = 2048, eos = 2150;
+    int* past = nullptr;    // [R][32] ring of emitted code_0
+    int* n_past = nullptr;  // [R]
+    const int* n_text = nullptr;  // [R]
+    int* done = nullptr;          // [R]
+    // codes of frame f of row r live at codes[(f*R + r)*16 .. +16); f = n_frames[r] (per-row counter,
+    // incremented here; clamped to frame_cap-1).  Column 0 is written: code_0, or -1 once the row finished.
+    int* codes = nullptr;
+    int* n_frames = nullptr;      // [R]
+    int frame_cap = 0;
+    const int* pos0 = nullptr;    // [R] prefix length
+    int* pos = nullptr;           // [R] position of the talker step that follows = pos0 + frames emitted before
+    int ignore_eos = 0;
+    int max_frames = 0;
+    float rep_penalty = 1.2f;
+};
+int launch_talker_sample(hipStream_t s, const TalkerSampleArgs& a);
+
+// Code-predictor group argmax (+ next embedding gather, or the feedback sum
+// of tts_client.py:199-208 after the last group).
+struct CpArgmaxArgs {
+    const float* logits = nullptr;  // [R][V]
+    int V = 0, R = 0, H = 0;
+    int group = 0;                 // writes column group+1 of the row's current frame
+    int* codes = nullptr;          // as in TalkerSampleArgs (frame = n_frames[r]-1)
+    const int* n_frames = nullptr;
+    int frame_cap = 0;
+    const float* next_table = nullptr;  // f32 [V][H] of this group, or null
+    float* h_out = nullptr;
+    float* ssq_out = nullptr;
+    // feedback (when talker_emb != null): h_out = talker_emb[code0] + sum_g cp_tables[g][code_{g+1}] + pad
+    const float* talker_emb = nullptr;
+    int talker_vocab = 0;
+    const float* const* cp_tables = nullptr;  // device array [n_groups]
+    const float* pad_embed = nullptr;
+    int n_groups = 15;
+};
+int launch_cp_argmax(hipStream_t s, const CpArgmaxArgs& a);
+
+// Stand-alone feedback sum (tts_client.py:199-208) for host-provided codes.
+int launch_feedback(hipStream_t s, const int* codes16, int R, const float* talker_emb, int talker_vocab,
+                    const float* const* cp_tables, int cp_vocab, int n_groups, const float* pad_embed,
+                    float* h_out, float* ssq_out, int H);
+
+}  // namespace q3

@@ -1,0 +1,82 @@
+// q3_model.h -- device-resident model, KV cache, workspaces and the layer-stack runner.
+#pragma once
+#include "q3_kernels.h"
+
+namespace q3 {
+
+struct DevLinear {
+    half_t* wp = nullptr;  // fragment-packed fp16
+    int N = 0, K = 0;
+};
+
+struct DevLayer {
+    DevLinear qkv, o, gu, down;
+    float *in_ln = nullptr, *post_ln = nullptr, *q_norm = nullptr, *k_norm = nullptr;
+};
+
+struct DevStack {
+    std::vector<DevLayer> L;
+    float* final_norm = nullptr;
+    int ffn = 0;
+    int nt = 0;  // non-temporal weight stream
+    size_t weight_bytes = 0;
+};
+
+struct Model {
+    ModelCfg cfg;
+    int device = 0;
+    bool has_talker = false, has_cp = false;
+    DevStack talker, cp;
+    float* talker_emb = nullptr;  // f32 [talker_vocab][hidden]
+    DevLinear talker_head;
+    std::vector<float*> cp_emb;   // f32 [cp_vocab][hidden] each
+    std::vector<DevLinear> cp_head;
+    const float** d_cp_emb_ptrs = nullptr;  // device array of the cp_emb pointers
+    float *rope_cos = nullptr, *rope_sin = nullptr;  // [max_pos][head_dim/2]
+    int max_pos = 0;
+    std::vector<void*> allocs;
+    size_t device_bytes = 0;
+};
+
+Model* model_load(const char* path, bool want_talker, bool want_cp);
+void model_free(Model* m);
+
+struct KVCache {
+    half_t *k = nullptr, *v = nullptr;
+    int n_layers = 0, n_slots = 0, n_kv = 0, n_ctx = 0, head_dim = 128;
+    size_t layer_stride() const { return (size_t)n_slots * n_kv * n_ctx * head_dim; }
+    size_t bytes() const { return layer_stride() * n_layers * sizeof(half_t) * 2; }
+};
+int kv_alloc(KVCache& kv, int n_layers, int n_slots, int n_kv, int n_ctx);
+void kv_free(KVCache& kv);
+
+// Activations of one stack pass over up to max_rows rows.
+struct Work {
+    int max_rows = 0, hidden = 0;
+    float *h = nullptr, *ssq = nullptr, *qkv = nullptr;
+    half_t *attn = nullptr, *act = nullptr;
+    float* hidden_f32 = nullptr;   // post-final-norm
+    half_t* hidden_f16 = nullptr;
+    float* logits = nullptr;       // [max_rows][max vocab]
+};
+int work_alloc(Work& w, const ModelCfg& c, int max_rows, int ffn, int max_vocab);
+void work_free(Work& w);
+
+struct RowMap {            // which (slot, position) each row feeds
+    const int* slot = nullptr;  // device [R] or null -> slot_base + r*slot_stride
+    const int* pos = nullptr;   // device [R] or null -> pos_base + r*pos_stride
+    int slot_base = 0, slot_stride = 0, pos_base = 0, pos_stride = 0;
+    bool same_slot_rows = false;  // rows depend on each other through the cache (prefill): split prep/attend
+};
+
+// Run every layer of `st` over R rows whose residual stream (+ssq partials) sits in w.h / w.ssq.
+int run_stack(hipStream_t s, const Model& m, const DevStack& st, Work& w, KVCache& kv, int R,
+              const RowMap& rm, int attn_threads);
+
+struct GraphExec {
+    hipGraph_t g = nullptr;
+    hipGraphExec_t e = nullptr;
+    void reset();
+};
+
+}  // namespace q3

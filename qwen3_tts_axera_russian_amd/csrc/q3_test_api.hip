@@ -1,0 +1,139 @@
+// q3_test_api.hip -- kernel-level entry points used only by tests/ (host arrays in, host arrays out).
+#include "q3_model.h"
+
+using namespace q3;
+
+namespace q3 {
+int set_linear_tuning(int K, int kbw);
+}
+
+namespace {
+struct DBuf {
+    void* p = nullptr;
+    ~DBuf() {
+        if (p) hipFree(p);
+    }
+    bool alloc(size_t n) { return hipMalloc(&p, n ? n : 16) == hipSuccess; }
+    bool up(const void* src, size_t n) { return alloc(n) && (n == 0 || hipMemcpy(p, src, n, hipMemcpyHostToDevice) == hipSuccess); }
+};
+}  // namespace
+
+extern "C" {
+
+int q3t_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int q3t_set_linear_tuning(int K, int kbw) { return set_linear_tuning(K, kbw); }
+
+// One linear launch.  W is row-major fp16 [N][K]; gateup != 0 means rows [0,N/2) are gate and
+// [N/2,N) up (tile-interleaved on the device like the model loader does).
+// pro: 0 = x16[M][K] fp16, 1 = RMSNorm(h[M][K], gamma, eps).
+// epi: 0 = y[M][N] store, 1 = h_io[M][N] += y with ssq_out[M][N/16], 2 = act_out[M][N/2] fp16.
+int q3t_linear(int M, int N, int K, const uint16_t* W, int gateup, int pro, int epi, const uint16_t* x16,
+               const float* h, const float* gamma, float eps, float* y_or_h_io, float* ssq_out, uint16_t* act_out,
+               int nt) {
+    hipStream_t s = nullptr;
+    DBuf dW, dWp, dx, dh, dssq, dg, dy, dso, dact;
+    if (!dW.up(W, (size_t)N * K * 2) || !dWp.alloc((size_t)N * K * 2)) return -1;
+    if (gateup) {
+        if (launch_pack_linear(s, (const half_t*)dW.p, N / 2, K, (half_t*)dWp.p, 0, 2)) return -1;
+        if (launch_pack_linear(s, (const half_t*)dW.p + (size_t)(N / 2) * K, N / 2, K, (half_t*)dWp.p, 1, 2)) return -1;
+    } else {
+        if (launch_pack_linear(s, (const half_t*)dW.p, N, K, (half_t*)dWp.p, 0, 1)) return -1;
+    }
+    LinArgs a;
+    a.wp = (const half_t*)dWp.p;
+    a.N = N;
+    a.K = K;
+    a.M = M;
+    a.nt = nt;
+    if (pro == PRO_F16) {
+        if (!dx.up(x16, (size_t)M * K * 2)) return -1;
+        a.x16 = (const half_t*)dx.p;
+    } else {
+        if (!dh.up(h, (size_t)M * K * 4) || !dssq.alloc((size_t)M * (K / 16) * 4) || !dg.up(gamma, (size_t)K * 4)) return -1;
+        if (launch_ssq_rows(s, (const float*)dh.p, (float*)dssq.p, M, K)) return -1;
+        a.h = (const float*)dh.p;
+        a.ssq = (const float*)dssq.p;
+        a.ssq_parts = K / 16;
+        a.gamma = (const float*)dg.p;
+        a.eps = eps;
+    }
+    if (epi == EPI_STORE) {
+        if (!dy.alloc((size_t)M * N * 4)) return -1;
+        a.y = (float*)dy.p;
+        a.ldy = N;
+    } else if (epi == EPI_RESID) {
+        if (!dy.up(y_or_h_io, (size_t)M * N * 4) || !dso.alloc((size_t)M * (N / 16) * 4)) return -1;
+        a.h_out = (float*)dy.p;
+        a.ssq_out = (float*)dso.p;
+    } else {
+        if (!dact.alloc((size_t)M * (N / 2) * 2)) return -1;
+        a.act = (half_t*)dact.p;
+    }
+    if (launch_linear(s, a, pro, epi)) return -1;
+    Q3_HIP(hipDeviceSynchronize(), -1);
+    if (epi == EPI_STORE || epi == EPI_RESID)
+        Q3_HIP(hipMemcpy(y_or_h_io, dy.p, (size_t)M * N * 4, hipMemcpyDeviceToHost), -1);
+    if (epi == EPI_RESID && ssq_out) Q3_HIP(hipMemcpy(ssq_out, dso.p, (size_t)M * (N / 16) * 4, hipMemcpyDeviceToHost), -1);
+    if (epi == EPI_SWIGLU) Q3_HIP(hipMemcpy(act_out, dact.p, (size_t)M * (N / 2) * 2, hipMemcpyDeviceToHost), -1);
+    return 0;
+}
+
+// Time `iters` back-to-back launches of one linear shape over `n_copies` distinct weight copies
+// (cold weights like the real layer walk).  Returns average microseconds per launch, <0 on error.
+float q3t_bench_linear(int M, int N, int K, int pro, int epi, int nt, int n_copies, int iters) {
+    hipStream_t s = nullptr;
+    if (hipStreamCreate(&s) != hipSuccess) return -1.f;
+    const size_t wbytes = (size_t)N * K * 2;
+    DBuf dW, dx, dh, dssq, dg, dy, dso, dact;
+    if (!dW.alloc(wbytes * n_copies)) return -1.f;
+    hipMemset(dW.p, 0x11, wbytes * n_copies);
+    dx.alloc((size_t)M * K * 2);
+    hipMemset(dx.p, 0, (size_t)M * K * 2);
+    dh.alloc((size_t)M * K * 4);
+    hipMemset(dh.p, 0, (size_t)M * K * 4);
+    dssq.alloc((size_t)M * (K / 16) * 4);
+    hipMemset(dssq.p, 0, (size_t)M * (K / 16) * 4);
+    dg.alloc((size_t)K * 4);
+    hipMemset(dg.p, 0, (size_t)K * 4);
+    dy.alloc((size_t)M * N * 4);
+    dso.alloc((size_t)M * (N / 16) * 4);
+    dact.alloc((size_t)M * (N / 2) * 2);
+    LinArgs a;
+    a.N = N;
+    a.K = K;
+    a.M = M;
+    a.nt = nt;
+    a.x16 = (const half_t*)dx.p;
+    a.h = (const float*)dh.p;
+    a.ssq = (const float*)dssq.p;
+    a.ssq_parts = K / 16;
+    a.gamma = (const float*)dg.p;
+    a.y = (float*)dy.p;
+    a.ldy = N;
+    a.h_out = (float*)dy.p;
+    a.ssq_out = (float*)dso.p;
+    a.act = (half_t*)dact.p;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int it = -n_copies; it < iters; it++) {
+        if (it == 0) hipEventRecord(e0, s);
+        a.wp = (const half_t*)((char*)dW.p + wbytes * (size_t)((it + n_copies) % n_copies));
+        if (launch_linear(s, a, pro, epi)) return -1.f;
+    }
+    hipEventRecord(e1, s);
+    if (hipStreamSynchronize(s) != hipSuccess) return -1.f;
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipStreamDestroy(s);
+    return ms * 1000.f / iters;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+"""Loader of the HIP shared library (the only compute path; there is no CPU fallback)."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from . import LIB_PATH
+
+_lib = None
+
+c_void_p, c_int, c_float, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_char_p
+f32p = ctypes.POINTER(ctypes.c_float)
+i32p = ctypes.POINTER(ctypes.c_int32)
+i64p = ctypes.POINTER(ctypes.c_int64)
+u16p = ctypes.POINTER(ctypes.c_uint16)
+i16p = ctypes.POINTER(ctypes.c_int16)
+
+
+def _sig(lib, name, restype, argtypes):
+    fn = getattr(lib, name)
+    fn.restype, fn.argtypes = restype, argtypes
+
+
+def load(path: str | None = None):
+    """dlopen libqwen3tts.so and declare every C-ABI signature of include/*.h."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("QWEN3TTS_LIB", LIB_PATH)
+    if not os.path.exists(p):
+        raise RuntimeError(f"{p} not found: build it with `python -m qwen3_tts_axera_russian_amd.build` "
+                           "(the HIP library is the only compute path)")
+    lib = ctypes.CDLL(p)
+    # include/qwen3tts_talker.h
+    _sig(lib, "wrapper_backend_init", None, [])
+    _sig(lib, "wrapper_backend_free", None, [])
+    _sig(lib, "wrapper_load_model", c_void_p, [c_char_p, c_int])
+    _sig(lib, "wrapper_free_model", None, [c_void_p])
+    _sig(lib, "wrapper_model_n_embd", c_int, [c_void_p])
+    _sig(lib, "wrapper_create_context", c_void_p, [c_void_p, c_int, c_int, c_int, c_int])
+    _sig(lib, "wrapper_create_context_slots", c_void_p, [c_void_p, c_int, c_int, c_int])
+    _sig(lib, "wrapper_free_context", None, [c_void_p])
+    _sig(lib, "wrapper_ctx_n_slots", c_int, [c_void_p])
+    _sig(lib, "wrapper_kv_clear", None, [c_void_p])
+    _sig(lib, "wrapper_decode_embd", c_int, [c_void_p, f32p, c_int, c_int, c_int, f32p])
+    _sig(lib, "wrapper_decode_embd_slot", c_int, [c_void_p, c_int, f32p, c_int, c_int, c_int, f32p])
+    _sig(lib, "wrapper_decode_embd_batch", c_int, [c_void_p, f32p, c_int, c_int, i32p, i32p, f32p])
+    _sig(lib, "wrapper_codec_head", c_int, [c_void_p, f32p, c_int, f32p])
+    _sig(lib, "wrapper_state_get_size", ctypes.c_size_t, [c_void_p])
+    _sig(lib, "wrapper_state_save_file", c_int, [c_void_p, c_char_p])
+    _sig(lib, "wrapper_state_load_file", c_int, [c_void_p, c_char_p])
+    # include/qwen3tts_cp.h
+    _sig(lib, "cp_load", c_void_p, [c_char_p, c_char_p, c_int])
+    _sig(lib, "cp_free", None, [c_void_p])
+    _sig(lib, "cp_hidden_size", c_int, [c_void_p])
+    _sig(lib, "cp_predict", c_int, [c_void_p, f32p, ctypes.c_int32, c_float, c_int, ctypes.c_uint64, i32p])
+    _sig(lib, "cp_predict_batch", c_int, [c_void_p, f32p, i32p, c_int, c_float, c_int, ctypes.c_uint64, i32p])
+    _sig(lib, "cp_step", c_int, [c_void_p, f32p, c_int, f32p])
+    _sig(lib, "cp_lm_head", c_int, [c_void_p, c_int, f32p, f32p])
+    # test hooks
+    _sig(lib, "q3t_device_count", c_int, [])
+    _sig(lib, "q3t_set_linear_tuning", c_int, [c_int, c_int])
+    _sig(lib, "q3t_linear", c_int, [c_int, c_int, c_int, u16p, c_int, c_int, c_int, u16p, f32p, f32p, c_float,
+                                    f32p, f32p, u16p, c_int])
+    _sig(lib, "q3t_bench_linear", c_float, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int])
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def fptr(a):
+    return a.ctypes.data_as(f32p)
+
+
+def iptr(a):
+    return a.ctypes.data_as(i32p)

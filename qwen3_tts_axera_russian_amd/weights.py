@@ -1,0 +1,328 @@
+"""Q3TTSW1 weight container: writer/reader, synthetic weights, converters.
+
+The reference ships no weights; its servers load GGUF (talker), .npy/.npz
+(tables, code predictor: scripts/extract_embeddings.py:47-98,
+scripts/export_code_predictor_weights.py:51-78) and ONNX (vocoder).  The HIP
+libraries load ONE self-describing container instead:
+
+    FileHeader  { char magic[8] = "Q3TTSW1\\0"; u32 version; u32 n_tensors;
+                  u32 n_meta; u32 reserved; u64 data_offset; }          32 B
+    Meta[n_meta]{ char key[48]; f64 value; }                           56 B each
+    Tensor[n]   { char name[96]; u32 dtype; u32 ndim; u64 shape[4];
+                  u64 offset; u64 nbytes; }                            152 B each
+    data (each tensor 256-B aligned, little-endian, C order)
+
+dtype: 0=f32 1=f16 2=i32 3=i64.  Names follow the HF checkpoint keys the
+reference's scripts read (talker.layers.N.q_proj ...), see `talker_tensor_names`.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import struct
+from dataclasses import dataclass, asdict, field
+
+import numpy as np
+
+MAGIC = b"Q3TTSW1\0"
+VERSION = 1
+DTYPES = {0: np.float32, 1: np.float16, 2: np.int32, 3: np.int64}
+DTYPE_CODE = {np.dtype(v): k for k, v in DTYPES.items()}
+_HDR = struct.Struct("<8sIIIIQ")
+_META = struct.Struct("<48sd")
+_TENS = struct.Struct("<96sII4QQQ")
+ALIGN = 256
+
+
+@dataclass
+class ModelConfig:
+    """Numeric model description stored in the container's meta table.
+
+    Defaults are Qwen3-TTS-12Hz-0.6B (scripts/extract_talker_as_qwen3.py:89-110,
+    dual_npu/llamacpp_talker_server.py:44-55, code_predictor_server.cpp:43-47).
+    """
+    hidden: int = 1024
+    head_dim: int = 128
+    n_heads: int = 16
+    n_kv_heads: int = 8
+    talker_layers: int = 28
+    talker_ffn: int = 3072
+    talker_vocab: int = 3072
+    cp_layers: int = 5
+    cp_ffn: int = 3072
+    cp_vocab: int = 2048
+    cp_groups: int = 15
+    rms_eps: float = 1e-6
+    rope_theta: float = 1e6
+    text_vocab: int = 151936
+    text_dim: int = 2048
+    # special ids (llamacpp_talker_server.py:44-55,132)
+    codec_pad: int = 2148
+    codec_bos: int = 2149
+    codec_eos: int = 2150
+    codec_nothink: int = 2155
+    codec_think_bos: int = 2156
+    codec_think_eos: int = 2157
+    tts_pad: int = 151671
+    tts_bos: int = 151672
+    tts_eos: int = 151673
+    im_start: int = 151644
+    assistant: int = 77091
+    newline: int = 198
+
+    def meta(self) -> dict:
+        return {k: float(v) for k, v in asdict(self).items()}
+
+    @staticmethod
+    def from_meta(meta: dict) -> "ModelConfig":
+        c = ModelConfig()
+        for k, v in meta.items():
+            if hasattr(c, k):
+                cur = getattr(c, k)
+                setattr(c, k, float(v) if isinstance(cur, float) else int(round(v)))
+        return c
+
+
+def tiny_config(talker_layers=2, cp_layers=2, text_vocab=512) -> ModelConfig:
+    """Small-depth variant for tests: same widths (the kernels are shaped for
+    them), fewer layers, a text table small enough to generate in a test."""
+    return ModelConfig(talker_layers=talker_layers, cp_layers=cp_layers, text_vocab=text_vocab,
+                       tts_pad=text_vocab - 3, tts_bos=text_vocab - 2, tts_eos=text_vocab - 1,
+                       im_start=text_vocab - 4, assistant=text_vocab - 5, newline=text_vocab - 6)
+
+
+# ----------------------------------------------------------------------------
+# container I/O
+# ----------------------------------------------------------------------------
+
+def write_pack(path: str, meta: dict, tensors: dict) -> None:
+    names = list(tensors.keys())
+    n_t, n_m = len(names), len(meta)
+    table_end = _HDR.size + n_m * _META.size + n_t * _TENS.size
+    data_off = (table_end + ALIGN - 1) // ALIGN * ALIGN
+    entries, off = [], data_off
+    for n in names:
+        a = tensors[n]
+        if a.dtype not in DTYPE_CODE:
+            raise TypeError(f"{n}: unsupported dtype {a.dtype}")
+        if a.ndim > 4:
+            raise ValueError(f"{n}: ndim>4")
+        shape = list(a.shape) + [0] * (4 - a.ndim)
+        entries.append((n, DTYPE_CODE[a.dtype], a.ndim, shape, off, a.nbytes))
+        off = (off + a.nbytes + ALIGN - 1) // ALIGN * ALIGN
+    tmp = path + ".tmp"
+    with open(tmp, "wb") as f:
+        f.write(_HDR.pack(MAGIC, VERSION, n_t, n_m, 0, data_off))
+        for k, v in meta.items():
+            f.write(_META.pack(k.encode()[:47], float(v)))
+        for n, dt, nd, shape, o, nb in entries:
+            f.write(_TENS.pack(n.encode()[:95], dt, nd, *shape, o, nb))
+        for (n, dt, nd, shape, o, nb) in entries:
+            f.seek(o)
+            np.ascontiguousarray(tensors[n]).tofile(f)
+        f.truncate(off)
+    os.replace(tmp, path)
+
+
+def read_pack(path: str, mmap: bool = True):
+    """-> (meta dict, {name: ndarray}).  Arrays are read-only memmaps."""
+    with open(path, "rb") as f:
+        magic, ver, n_t, n_m, _, data_off = _HDR.unpack(f.read(_HDR.size))
+        if magic != MAGIC or ver != VERSION:
+            raise ValueError(f"{path}: not a Q3TTSW1 v{VERSION} container")
+        meta = {}
+        for _ in range(n_m):
+            k, v = _META.unpack(f.read(_META.size))
+            meta[k.split(b"\0")[0].decode()] = v
+        ents = []
+        for _ in range(n_t):
+            rec = _TENS.unpack(f.read(_TENS.size))
+            ents.append((rec[0].split(b"\0")[0].decode(), rec[1], rec[2], rec[3:7], rec[7], rec[8]))
+    tensors = {}
+    for n, dt, nd, shape, off, nb in ents:
+        shp = tuple(int(s) for s in shape[:nd])
+        if mmap:
+            tensors[n] = np.memmap(path, dtype=DTYPES[dt], mode="r", offset=off, shape=shp)
+        else:
+            tensors[n] = np.fromfile(path, dtype=DTYPES[dt], offset=off, count=int(np.prod(shp))).reshape(shp)
+    return meta, tensors
+
+
+# ----------------------------------------------------------------------------
+# tensor inventory
+# ----------------------------------------------------------------------------
+
+LAYER_PARTS = ("input_ln", "q_proj", "k_proj", "v_proj", "o_proj", "q_norm", "k_norm",
+               "post_ln", "gate_proj", "up_proj", "down_proj")
+
+
+def layer_shapes(cfg: ModelConfig, ffn: int) -> dict:
+    H, D = cfg.hidden, cfg.head_dim
+    return {"input_ln": (H,), "q_proj": (cfg.n_heads * D, H), "k_proj": (cfg.n_kv_heads * D, H),
+            "v_proj": (cfg.n_kv_heads * D, H), "o_proj": (H, cfg.n_heads * D), "q_norm": (D,),
+            "k_norm": (D,), "post_ln": (H,), "gate_proj": (ffn, H), "up_proj": (ffn, H),
+            "down_proj": (H, ffn)}
+
+
+def talker_tensor_shapes(cfg: ModelConfig) -> dict:
+    s = {}
+    for i in range(cfg.talker_layers):
+        for p, shp in layer_shapes(cfg, cfg.talker_ffn).items():
+            s[f"talker.layers.{i}.{p}"] = shp
+    s["talker.norm"] = (cfg.hidden,)
+    s["talker.codec_embedding"] = (cfg.talker_vocab, cfg.hidden)
+    s["talker.codec_head"] = (cfg.talker_vocab, cfg.hidden)
+    return s
+
+
+def cp_tensor_shapes(cfg: ModelConfig) -> dict:
+    s = {}
+    for i in range(cfg.cp_layers):
+        for p, shp in layer_shapes(cfg, cfg.cp_ffn).items():
+            s[f"cp.layers.{i}.{p}"] = shp
+    s["cp.norm"] = (cfg.hidden,)
+    for g in range(cfg.cp_groups):
+        s[f"cp.codec_emb.{g}"] = (cfg.cp_vocab, cfg.hidden)
+        s[f"cp.lm_head.{g}"] = (cfg.cp_vocab, cfg.hidden)
+    return s
+
+
+def text_tensor_shapes(cfg: ModelConfig) -> dict:
+    return {"text.embedding": (cfg.text_vocab, cfg.text_dim),
+            "text.fc1.weight": (cfg.text_dim, cfg.text_dim), "text.fc1.bias": (cfg.text_dim,),
+            "text.fc2.weight": (cfg.hidden, cfg.text_dim), "text.fc2.bias": (cfg.hidden,)}
+
+
+def _rng_for(name: str, seed: int) -> np.random.Generator:
+    h = hashlib.sha256(f"{seed}:{name}".encode()).digest()
+    return np.random.default_rng(int.from_bytes(h[:8], "little"))
+
+
+def _is_norm(name: str) -> bool:
+    return name.endswith(("input_ln", "post_ln", "q_norm", "k_norm", ".norm"))
+
+
+def synth_tensor(name: str, shape, seed: int, std: float = 0.02, table_dtype=np.float32):
+    """Deterministic synthetic tensor: N(0, std^2) per tensor-name
+    hash; norm weights 1 + N(0, 0.1^2) so the scale path is exercised.
+    Projection matrices are stored fp16 (what the device streams); tables and
+    norm vectors stay f32 (they are gathered / applied in f32)."""
+    rng = _rng_for(name, seed)
+    if _is_norm(name):
+        return (1.0 + 0.1 * rng.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+    if name.endswith("bias"):
+        return (std * rng.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+    a = std * rng.standard_normal(shape, dtype=np.float32)
+    if "codec_emb" in name or name == "text.embedding":
+        return a.astype(table_dtype)
+    if name.startswith("text.fc"):
+        return a.astype(np.float32)
+    return a.astype(np.float16)
+
+
+def make_synthetic(cfg: ModelConfig, seed: int = 1234, parts=("talker", "cp", "text"),
+                   text_table_dtype=np.float32) -> dict:
+    shapes = {}
+    if "talker" in parts:
+        shapes.update(talker_tensor_shapes(cfg))
+    if "cp" in parts:
+        shapes.update(cp_tensor_shapes(cfg))
+    if "text" in parts:
+        shapes.update(text_tensor_shapes(cfg))
+    return {n: synth_tensor(n, shp, seed, table_dtype=text_table_dtype if n == "text.embedding" else np.float32)
+            for n, shp in shapes.items()}
+
+
+def write_synthetic(path: str, cfg: ModelConfig, seed: int = 1234, parts=("talker", "cp", "text"),
+                    extra: dict | None = None, text_table_dtype=np.float32) -> None:
+    t = make_synthetic(cfg, seed, parts, text_table_dtype)
+    if extra:
+        t.update(extra)
+    write_pack(path, cfg.meta(), t)
+
+
+# ----------------------------------------------------------------------------
+# converters from the formats the reference deploys
+# ----------------------------------------------------------------------------
+
+def from_reference_dirs(embeddings_dir: str, cp_dir: str, talker_safetensors: str | None,
+                        out_path: str, cfg: ModelConfig | None = None) -> None:
+    """Pack the reference's deployed files (README.md:108-122):
+    embeddings/{text_embedding,codec_embedding,codec_head,text_projection_*}.npy
+    (scripts/extract_embeddings.py:47-72), code_predictor_weights.npz
+    (scripts/export_code_predictor_weights.py:51-78) and the re-keyed talker
+    safetensors (scripts/extract_talker_as_qwen3.py:53-71) into one container."""
+    cfg = cfg or ModelConfig()
+    t = {}
+    e = lambda n: np.load(os.path.join(embeddings_dir, n))
+    t["text.embedding"] = e("text_embedding.npy").astype(np.float32)
+    t["text.fc1.weight"] = e("text_projection_linear_fc1_weight.npy").astype(np.float32)
+    t["text.fc1.bias"] = e("text_projection_linear_fc1_bias.npy").astype(np.float32)
+    t["text.fc2.weight"] = e("text_projection_linear_fc2_weight.npy").astype(np.float32)
+    t["text.fc2.bias"] = e("text_projection_linear_fc2_bias.npy").astype(np.float32)
+    t["talker.codec_embedding"] = e("codec_embedding.npy").astype(np.float32)
+    t["talker.codec_head"] = e("codec_head.npy").astype(np.float16)
+    w = np.load(os.path.join(cp_dir, "code_predictor_weights.npz"))
+    for i in range(cfg.cp_layers):
+        for p in LAYER_PARTS:
+            a = w[f"layer_{i}_{p}"]
+            t[f"cp.layers.{i}.{p}"] = a.astype(np.float32 if a.ndim == 1 else np.float16)
+    t["cp.norm"] = w["final_norm"].astype(np.float32)
+    for g in range(cfg.cp_groups):
+        t[f"cp.codec_emb.{g}"] = w[f"codec_emb_{g}"].astype(np.float32)
+        t[f"cp.lm_head.{g}"] = w[f"lm_head_{g}"].astype(np.float16)
+    if talker_safetensors:
+        t.update(_talker_from_safetensors(talker_safetensors, cfg, "model.layers.", "model.norm.weight"))
+    write_pack(out_path, cfg.meta(), t)
+
+
+_HF_PART = {"input_ln": "input_layernorm.weight", "q_proj": "self_attn.q_proj.weight",
+            "k_proj": "self_attn.k_proj.weight", "v_proj": "self_attn.v_proj.weight",
+            "o_proj": "self_attn.o_proj.weight", "q_norm": "self_attn.q_norm.weight",
+            "k_norm": "self_attn.k_norm.weight", "post_ln": "post_attention_layernorm.weight",
+            "gate_proj": "mlp.gate_proj.weight", "up_proj": "mlp.up_proj.weight",
+            "down_proj": "mlp.down_proj.weight"}
+
+
+def _talker_from_safetensors(path, cfg, layer_prefix, norm_key):
+    from safetensors import safe_open
+    t = {}
+    with safe_open(path, framework="np") as f:
+        for i in range(cfg.talker_layers):
+            for p, hf in _HF_PART.items():
+                a = f.get_tensor(f"{layer_prefix}{i}.{hf}")
+                t[f"talker.layers.{i}.{p}"] = a.astype(np.float32 if a.ndim == 1 else np.float16)
+        t["talker.norm"] = f.get_tensor(norm_key).astype(np.float32)
+    return t
+
+
+def from_hf_checkpoint(model_dir: str, out_path: str, cfg: ModelConfig | None = None) -> None:
+    """Pack straight from the HF snapshot (Qwen/Qwen3-TTS-12Hz-0.6B-Base,
+    model.safetensors) using the key names the reference's scripts read
+    (scripts/extract_embeddings.py:47-98, export_code_predictor_weights.py:44-74)."""
+    import torch  # bf16 tensors need torch to decode
+    from safetensors.torch import load_file
+    cfg = cfg or ModelConfig()
+    w = load_file(os.path.join(model_dir, "model.safetensors"))
+    f32 = lambda k: w[k].float().numpy()
+    t = {}
+    for i in range(cfg.talker_layers):
+        for p, hf in _HF_PART.items():
+            a = f32(f"talker.model.layers.{i}.{hf}")
+            t[f"talker.layers.{i}.{p}"] = a.astype(np.float32 if a.ndim == 1 else np.float16)
+    t["talker.norm"] = f32("talker.model.norm.weight")
+    t["talker.codec_embedding"] = f32("talker.model.codec_embedding.weight")
+    t["talker.codec_head"] = f32("talker.codec_head.weight").astype(np.float16)
+    for i in range(cfg.cp_layers):
+        for p, hf in _HF_PART.items():
+            a = f32(f"talker.code_predictor.model.layers.{i}.{hf}")
+            t[f"cp.layers.{i}.{p}"] = a.astype(np.float32 if a.ndim == 1 else np.float16)
+    t["cp.norm"] = f32("talker.code_predictor.model.norm.weight")
+    for g in range(cfg.cp_groups):
+        t[f"cp.codec_emb.{g}"] = f32(f"talker.code_predictor.model.codec_embedding.{g}.weight")
+        t[f"cp.lm_head.{g}"] = f32(f"talker.code_predictor.lm_head.{g}.weight").astype(np.float16)
+    t["text.embedding"] = f32("talker.model.text_embedding.weight")
+    for fc in ("fc1", "fc2"):
+        t[f"text.{fc}.weight"] = f32(f"talker.text_projection.linear_{fc}.weight")
+        t[f"text.{fc}.bias"] = f32(f"talker.text_projection.linear_{fc}.bias")
+    write_pack(out_path, cfg.meta(), t)
