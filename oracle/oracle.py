@@ -39,9 +39,26 @@ def build(force: bool = False) -> str:
     return so
 
 
+def _limit_threads():
+    """The GPU box gives this job a CPU share of a much larger host: cap OpenMP so the oracle does
+    not oversubscribe (it gets slower by orders of magnitude when it does)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(8, n))))
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+
+def n_threads() -> int:
+    _limit_threads()
+    return int(os.environ["OMP_NUM_THREADS"])
+
+
 def lib():
     global _LIB
     if _LIB is None:
+        _limit_threads()
         L = ctypes.CDLL(build())
         L.orc_round_f16.restype = ctypes.c_float
         L.orc_round_f16.argtypes = [ctypes.c_float]

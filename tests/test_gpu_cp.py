@@ -1,0 +1,87 @@
+"""Code-predictor boundary (cp_* ABI) against the CPU oracle: greedy codec ids must be identical
+(bit-exact integers); a mismatch is tolerated only where the oracle's own top-1/top-2 logit gap
+is below 1e-4 (a float near-tie), and the per-position hidden must agree within 5e-3."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from qwen3_tts_axera_russian_amd.llama_cpp_bindings import CodePredictor
+from tests.util import rel_err, synthetic_pack
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup():
+    path, cfg, tensors = synthetic_pack(2, 2)
+    return path, cfg, tensors, orc.CpOracle(cfg, tensors)
+
+
+def _check_codes(got, ref_codes, margins):
+    got = np.asarray(got)
+    if np.array_equal(got, ref_codes):
+        return
+    g = int(np.nonzero(got != ref_codes)[0][0])
+    assert margins[g] < 1e-4, f"codes diverge at group {g} with oracle margin {margins[g]}: {got} vs {ref_codes}"
+
+
+def test_cp_predict_greedy_matches_oracle(gpu_lib, setup):
+    path, cfg, tensors, ref = setup
+    cp = CodePredictor(path, max_batch=1)
+    rng = np.random.default_rng(10)
+    min_margin = 1e9
+    for case in range(6):
+        hidden = rng.standard_normal(1024).astype(np.float32)
+        code0 = int(rng.integers(0, 2048))
+        got = cp.predict(hidden, code0)
+        codes, margins = ref.predict(hidden, code0)
+        _check_codes(got, codes, margins)
+        min_margin = min(min_margin, float(margins.min()))
+        assert all(0 <= c < 2048 for c in got)
+    print("cp min oracle margin:", min_margin)
+    # the reference's warm-up input (code_predictor_server.cpp:510-518): hidden = 0.1, code_0 = 100
+    w = np.full(1024, 0.1, np.float32)
+    codes, margins = ref.predict(w, 100)
+    _check_codes(cp.predict(w, 100), codes, margins)
+    # out-of-range code_0 embeds as zeros (code_predictor_server.cpp:269-272)
+    codes, margins = ref.predict(w, 5000)
+    _check_codes(cp.predict(w, 5000), codes, margins)
+    cp.destroy()
+
+
+def test_cp_step_hidden_matches_oracle(gpu_lib, setup):
+    path, cfg, tensors, ref = setup
+    cp = CodePredictor(path, max_batch=1)
+    rng = np.random.default_rng(11)
+    hidden = rng.standard_normal(1024).astype(np.float32)
+    code0 = 321
+    codes, margins, hid = ref.predict(hidden, code0, want_hidden=True)
+    cp.step(hidden, 0)
+    emb = np.asarray(tensors["talker.codec_embedding"][code0], np.float32)
+    errs = []
+    for g in range(15):
+        h = cp.step(emb, g + 1)
+        errs.append(rel_err(h, hid[g]))
+        lg = cp.lm_head(g, h)
+        assert int(np.argmax(lg)) == codes[g] or margins[g] < 1e-4
+        emb = np.asarray(tensors[f"cp.codec_emb.{g}"][codes[g]], np.float32) if g < 14 else None
+    print("cp step rel errs:", ["%.1e" % e for e in errs])
+    assert max(errs) < 5e-3
+    cp.destroy()
+
+
+def test_cp_batch_equals_single(gpu_lib, setup):
+    path, cfg, tensors, ref = setup
+    cpb = CodePredictor(path, max_batch=8)
+    rng = np.random.default_rng(12)
+    for R in (1, 5, 8):
+        hidden = rng.standard_normal((R, 1024)).astype(np.float32)
+        code0 = rng.integers(0, 2048, size=R).astype(np.int32)
+        got = cpb.predict_batch(hidden, code0)
+        assert got.shape == (R, 15)
+        for r in range(R):
+            codes, margins = ref.predict(hidden[r], int(code0[r]))
+            _check_codes(got[r], codes, margins)
+    with pytest.raises(RuntimeError):
+        cpb.predict_batch(np.zeros((9, 1024), np.float32), np.zeros(9, np.int32))
+    cpb.destroy()
