@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X Qwen3-TTS hot path (BASELINE.json metric: RTF + 12 Hz codec-tokens/s).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one batch of synthetic utterances: ragged prefill of B
+prompts + F autoregressive frames (talker step, 15-group code predictor, feedback) for all of them
+[+ the vocoder chunk of every utterance once the vocoder library is present], inputs (weights,
+prefix embeddings) resident in HBM/host-pinned before the timed region.  Utterances are independent:
+N GPUs = N replicas of the per-GPU batch, no collective on the data path (weak scaling); the only
+torch.distributed traffic is the barrier and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line on rank 0.  Weights are random-init tensors of the Qwen3-TTS-0.6B architecture
+(no checkpoint can exist here), decode is greedy with EOS suppressed so the frame count is fixed.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FRAME_SEC = 1920.0 / 24000.0      # one codec frame = 80 ms of audio (vocoder_server.py:29-30)
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# token counts of the fixed mixed ru/en prompt set (5-40 tokens each; the first is the
+# reference's default prompt, tts_client.py:291, which tokenises to ~17 Qwen tokens)
+PROMPT_TOKENS = [17, 9, 24, 31, 12, 38, 7, 19, 27, 14, 35, 22, 5, 29, 16, 40,
+                 11, 33, 8, 21, 26, 13, 37, 18, 6, 30, 15, 39, 10, 23, 28, 20]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (config 3/4: 32)")
+    ap.add_argument("--frames", type=int, default=64, help="frames per utterance per step (one vocoder chunk)")
+    ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 latency leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-frames", type=int, default=12)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--cache", default=os.environ.get("Q3_BENCH_CACHE", "/tmp/q3_bench_cache"))
+    return ap.parse_args()
+
+
+def make_pack(cache, seed, rank, barrier):
+    from qwen3_tts_axera_russian_amd import weights as W
+    os.makedirs(cache, exist_ok=True)
+    cfg = W.ModelConfig()
+    path = os.path.join(cache, f"qwen3tts06b_synth_s{seed}.q3w")
+    if rank == 0 and not os.path.exists(path):
+        t = time.time()
+        W.write_synthetic(path, cfg, seed=seed, parts=("talker", "cp"))
+        print(f"[bench] wrote synthetic Qwen3-TTS-0.6B weights ({os.path.getsize(path)/1e9:.2f} GB) in "
+              f"{time.time()-t:.0f}s", file=sys.stderr, flush=True)
+    barrier()
+    return path, cfg
+
+
+def workload(B, rank, seed):
+    """B prompts of the fixed set (offset by rank): prefix rows = n_text + 9 (llamacpp_talker_server.py:121-161)."""
+    rng = np.random.default_rng(seed + 1000 * rank)
+    n_text = [PROMPT_TOKENS[(rank * B + b) % len(PROMPT_TOKENS)] for b in range(B)]
+    prefixes = [(0.03 * rng.standard_normal((n + 9, 1024))).astype(np.float32) for n in n_text]
+    pad = (0.03 * rng.standard_normal(1024)).astype(np.float32)
+    return prefixes, n_text, pad
+
+
+def run_leg(eng, prefixes, n_text, pad, frames, steps, warmup, sync_all):
+    """-> (wall seconds for `steps` steps, mean GPU ms per frame step, mean prefill ms)."""
+    eng.set_pad_embed(pad)
+    for _ in range(warmup):
+        eng.start(prefixes, n_text, ignore_eos=True, max_frames=frames)
+        eng.run(frames)
+    frame_ms, prefill_ms = [], []
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.start(prefixes, n_text, ignore_eos=True, max_frames=frames)
+        ran = eng.run(frames)
+        assert ran == frames
+        frame_ms.append(eng.last_run_ms / frames)
+        prefill_ms.append(eng.last_prefill_ms)
+    sync_all()
+    dt = time.perf_counter() - t0
+    return dt, float(np.mean(frame_ms)), float(np.mean(prefill_ms))
+
+
+def kv_bytes_per_step(n_text, frames, cfg):
+    """Algorithmic KV reads of one frame step, averaged over the run: talker
+    114688 B x T per utterance, CP <= 20480 B x 16 per position."""
+    per_pos = cfg.talker_layers * 2 * cfg.n_kv_heads * cfg.head_dim * 2
+    t_avg = [n + 9 + frames / 2.0 for n in n_text]
+    cp = cfg.cp_layers * 2 * cfg.n_kv_heads * cfg.head_dim * 2 * sum(range(1, 17))
+    return sum(per_pos * t for t in t_avg) + cp * len(n_text)
+
+
+def cpu_baseline(path, cfg, prefix, n_text, pad, frames):
+    """The CPU restatement (oracle/, the 'port' baseline) on a bounded sample of the same workload."""
+    from oracle import oracle as orc
+    from oracle.pipeline import CpuPipeline
+    from qwen3_tts_axera_russian_amd import weights as W
+    threads = orc.n_threads()
+    _, tensors = W.read_pack(path)
+    pipe = CpuPipeline(cfg, tensors, n_ctx=prefix.shape[0] + frames + 1)
+    t0 = time.perf_counter()
+    out = pipe.generate(prefix, n_text, pad, frames, ignore_eos=True)
+    dt = time.perf_counter() - t0
+    assert len(out) == frames
+    return {"value": round(frames / dt, 3), "unit": "codec_frames/s", "cores": threads, "kind": "port",
+            "rtf": round(dt / (frames * FRAME_SEC), 3),
+            "sample": f"1 utterance, prefill {prefix.shape[0]} rows + {frames} frames (talker+code predictor, "
+                      f"fp32 C/OpenMP restatement of the same fp16-weight contract), {dt:.1f}s"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    from qwen3_tts_axera_russian_amd import hiplib
+    from qwen3_tts_axera_russian_amd.engine import FrameEngine
+    lib = hiplib.load()
+    if lib.q3t_device_count() <= 0:
+        raise SystemExit("bench.py: no HIP device -- the HIP library is the only compute path")
+    lib.q3_set_device(local_rank % lib.q3t_device_count())
+
+    def sync_all():
+        # engine calls are synchronous (each q3e_run ends with a stream sync); ranks meet at the barrier
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    path, cfg = make_pack(a.cache, a.seed, rank, barrier)
+    B, F = a.batch, a.frames
+    prefixes, n_text, pad = workload(B, rank, a.seed)
+    n_ctx = max(p.shape[0] for p in prefixes) + F + 8
+    eng = FrameEngine(path, max_batch=B, n_ctx=n_ctx, max_frames=F)
+    dt, frame_ms, prefill_ms = run_leg(eng, prefixes, n_text, pad, F, a.steps, a.warmup, sync_all)
+    step_w_bytes = eng.step_weight_bytes
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_frames = world * B * F * a.steps
+    value = total_frames / dt
+    ms_per_step = dt / a.steps * 1e3
+    algo_bytes = step_w_bytes + kv_bytes_per_step(n_text, F, cfg)
+    achieved = algo_bytes / (frame_ms * 1e-3) / 1e9
+    out = {
+        "metric": "12Hz codec-tokens/s (codec frames/s, 16 codes each) + RTF, Qwen3-TTS-0.6B",
+        "value": round(value, 1), "unit": "codec_frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16 weights/KV, f32 accumulate (talker+CP)", "data": "synthetic (random-init weights of the "
+        "0.6B architecture, seeded prefix embeddings, greedy, EOS suppressed)",
+        "config": {"workload": f"configs[2]/[3]: batch={B} mixed ru/en prompts per GPU, {F} frames/utterance/step "
+                               f"(prefill + hipGraph decode loop), utterance-sharded DP over {world} GPU(s)",
+                   "batch_per_gpu": B, "frames_per_step": F, "prompt_tokens": "5-40 (fixed set)"},
+        "rtf": round((dt / a.steps) / (F * FRAME_SEC), 5),
+        "rtf_aggregate": round((dt / a.steps) / (world * B * F * FRAME_SEC), 6),
+        "prefill_ms": round(prefill_ms, 3),
+        "roofline": {"kernel": "frame-step hipGraph (talker 28L + 16 CP passes + heads)", "bound": "hbm",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(frame_ms, 4)},
+    }
+    eng.destroy()
+    if world == 1 and not a.no_b1:
+        eng1 = FrameEngine(path, max_batch=1, n_ctx=n_ctx, max_frames=F)
+        dt1, frame_ms1, prefill_ms1 = run_leg(eng1, prefixes[:1], n_text[:1], pad, F, a.steps, a.warmup, sync_all)
+        ab1 = step_w_bytes + kv_bytes_per_step(n_text[:1], F, cfg)
+        out["batch1"] = {"workload": "configs[1]: batch=1, same engine", "value": round(F * a.steps / dt1, 1),
+                         "unit": "codec_frames/s", "rtf": round((dt1 / a.steps) / (F * FRAME_SEC), 5),
+                         "ms_per_frame": round(frame_ms1, 4), "prefill_ms": round(prefill_ms1, 3),
+                         "hbm_frac": round(ab1 / (frame_ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        eng1.destroy()
+    if rank == 0 and world == 1 and not a.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(path, cfg, prefixes[0], n_text[0], pad, a.cpu_frames)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

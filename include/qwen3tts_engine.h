@@ -1,0 +1,61 @@
+/*
+ * qwen3tts_engine.h -- C ABI of the fused on-device frame loop (batch mode).
+ *
+ * Not present in the reference: there the autoregressive loop is closed by the Python client
+ * over two sockets per frame (dual_npu/tts_client.py:144-215): talker hidden + code_0
+ * (llamacpp_talker_server.py:254-293) -> code predictor (code_predictor_server.py:94-140)
+ * -> feedback embedding (tts_client.py:199-208) -> next talker step.  This library keeps that
+ * whole cycle on the GPU for B independent utterances: per frame one
+ * hipGraph launch; the host only reads the codec ids.  Greedy decoding (the reference's
+ * --temperature 0 limit); EOS rule, EOS boost, repetition penalty and the 2048..2149 / >=2151
+ * mask are those of llamacpp_talker_server.py:163-206,258.
+ *
+ * Caller-owned host buffers, synchronous calls, one caller thread per handle, no CPU fallback.
+ */
+#ifndef QWEN3TTS_ENGINE_H
+#define QWEN3TTS_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* weights: Q3TTSW1 container with talker.* and cp.*.  max_batch utterances at once, n_ctx talker
+ * positions per utterance (prefix + frames), max_frames frames kept per utterance. */
+void* q3e_create(const char* weights, int max_batch, int n_ctx, int max_frames);
+void q3e_free(void* e);
+
+/* tts_pad embedding added to every feedback (tts_client.py:207-208); zeros until set. */
+int q3e_set_pad_embed(void* e, const float* pad_embed /*[hidden]*/);
+
+/* Begin a batch of B utterances.  prefix: the dual-stream prefix rows of all utterances,
+ * concatenated ([sum n_rows][hidden] f32, llamacpp_talker_server.py:121-161); n_rows[b] rows
+ * belong to utterance b; n_text[b] = number of text tokens (EOS heuristics, :172-181).
+ * ignore_eos != 0 suppresses EOS (fixed-length benchmarking); max_frames caps every utterance
+ * (the server's --max_tokens).  Runs the prefill; 0 ok / <0 error. */
+int q3e_start(void* e, int B, const float* prefix, const int32_t* n_rows, const int32_t* n_text,
+              int ignore_eos, int max_frames);
+
+/* Generate up to n_frames more frames for the whole batch (returns early once every utterance
+ * has finished).  Returns the number of frame steps executed, <0 on error. */
+int q3e_run(void* e, int n_frames);
+
+/* GPU time of the last q3e_run / q3e_start in milliseconds (HIP events on the engine's stream). */
+float q3e_last_run_ms(void* e);
+float q3e_last_prefill_ms(void* e);
+
+/* Codes so far: out[f][b][16] for f < returned frame count (<= max_out_frames); rows of finished
+ * utterances hold -1 in column 0.  n_frames_per_utt[b] = frames utterance b really emitted. */
+int q3e_get_codes(void* e, int32_t* out, int max_out_frames, int32_t* n_frames_per_utt);
+
+/* Talker hidden state of every utterance after the last executed step ([B][hidden]). */
+int q3e_get_hidden(void* e, float* out);
+
+/* Algorithmic weight bytes one frame step streams (talker stack + head + 16 CP passes + 15 heads). */
+double q3e_step_weight_bytes(void* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QWEN3TTS_ENGINE_H */

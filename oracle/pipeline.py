@@ -1,0 +1,52 @@
+"""Reference-shaped CPU pipeline: talker -> sample -> code predictor -> feedback, one utterance.
+TEST INFRASTRUCTURE ONLY (checker for the fused engine, and the timed CPU baseline of bench.py).
+
+The loop is the one the reference runs across its three processes: llamacpp_talker_server.py:254-293
+(sample, break on EOS / >= 2048, feed the feedback back), code_predictor_server.py:94-140,
+tts_client.py:199-208."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import frontend as fe
+from . import oracle as orc
+
+
+class CpuPipeline:
+    def __init__(self, cfg, tensors, n_ctx=512):
+        self.cfg = cfg
+        self.talker = orc.TalkerOracle(cfg, tensors, n_ctx=n_ctx)
+        self.cp = orc.CpOracle(cfg, tensors)
+        self.codec_embedding = self.talker.codec_embedding
+        self.cp_emb = self.cp.emb
+
+    def generate(self, prefix, n_text, pad_embed, max_frames, ignore_eos=False, want_margins=False):
+        """-> frames list of 16 ints (and, if asked, per-frame [16] top-1/top-2 logit gaps; the entry
+        after the last frame holds the gap of the terminating EOS decision in column 0)."""
+        cfg = self.cfg
+        self.talker.clear()
+        hidden = self.talker.forward(prefix, 0)
+        pos = prefix.shape[0]
+        past, frames, margins_all = [], [], []
+        for _ in range(max_frames):
+            logits = self.talker.logits(hidden)
+            if ignore_eos:
+                lg, _ = fe.process_talker_logits(logits, past, n_text, cfg.codec_eos)
+                lg[cfg.codec_eos] = -1e10
+                code0 = int(np.argmax(lg))
+            else:
+                lg, forced = fe.process_talker_logits(logits, past, n_text, cfg.codec_eos)
+                code0 = int(forced) if forced is not None else int(np.argmax(lg))
+            srt = np.sort(lg)
+            m0 = float(srt[-1] - srt[-2])
+            if code0 == cfg.codec_eos or code0 >= 2048:
+                margins_all.append([m0] + [np.inf] * 15)
+                break
+            codes, margins = self.cp.predict(hidden, code0)
+            margins_all.append([m0] + [float(x) for x in margins])
+            frames.append([code0] + [int(c) for c in codes])
+            past.append(code0)
+            fb = fe.feedback_embedding(code0, codes, self.codec_embedding, self.cp_emb, pad_embed)
+            hidden = self.talker.forward(fb, pos)
+            pos += 1
+        return (frames, margins_all) if want_margins else frames

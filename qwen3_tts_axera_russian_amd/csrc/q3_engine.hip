@@ -1,0 +1,355 @@
+// q3_engine.hip -- fused on-device frame loop for B utterances (include/qwen3tts_engine.h).
+//
+// One frame = [talker_sample -> 16 code-predictor positions (+15 heads/argmax) -> feedback sum ->
+// talker step -> final norm -> codec head], captured once per batch size as a hipGraph.  All
+// per-utterance state (positions, EOS bookkeeping, emitted codes) lives in device arrays so the
+// same graph serves every frame.
+#include "../../include/qwen3tts_engine.h"
+#include "q3_cp.h"
+
+using namespace q3;
+
+namespace {
+
+struct Engine {
+    Model* m = nullptr;
+    int max_batch = 0, n_ctx = 0, max_frames = 0;
+    hipStream_t s = nullptr;
+    KVCache kv_t, kv_c;
+    Work wt, wc;  // talker / code-predictor activations
+    int prefill_rows = 0;
+    // device state
+    int *d_slot = nullptr, *d_pos = nullptr;       // prefill row maps [prefill_rows]
+    int *d_iota = nullptr;                         // [max_batch]
+    int *d_past = nullptr, *d_npast = nullptr, *d_ntext = nullptr, *d_done = nullptr, *d_nframes = nullptr;
+    int *d_pos0 = nullptr, *d_posdec = nullptr, *d_lastrow = nullptr;
+    int* d_codes = nullptr;  // [max_frames][B][16]
+    float* d_pad = nullptr;
+    // run state
+    int B = 0, ignore_eos = 0, cap_frames = 0, frames_run = 0;
+    GraphExec graph;
+    int graph_B = 0, graph_ignore = -1, graph_cap = -1;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_run_ms = 0.f, last_prefill_ms = 0.f;
+    int* h_done = nullptr;  // pinned [max_batch]
+};
+
+int talker_tail(Engine* e, int R, const int* row_map) {
+    // final norm (+ CP seed copy) and codec head for R rows
+    const Model& m = *e->m;
+    const int H = m.cfg.hidden;
+    FinalNormArgs f;
+    f.h = e->wt.h;
+    f.ssq = e->wt.ssq;
+    f.ssq_parts = H / 16;
+    f.gamma = m.talker.final_norm;
+    f.eps = m.cfg.eps;
+    f.R = R;
+    f.H = H;
+    f.row_map = row_map;
+    f.out_f32 = e->wt.hidden_f32;
+    f.out_f16 = e->wt.hidden_f16;
+    f.out_copy = e->wc.h;
+    f.out_copy_ssq = e->wc.ssq;
+    if (launch_final_norm(e->s, f)) return -1;
+    LinArgs a;
+    a.wp = m.talker_head.wp;
+    a.N = m.cfg.talker_vocab;
+    a.K = H;
+    a.M = R;
+    a.nt = 1;
+    a.x16 = e->wt.hidden_f16;
+    a.y = e->wt.logits;
+    a.ldy = m.cfg.talker_vocab;
+    return launch_linear(e->s, a, PRO_F16, EPI_STORE);
+}
+
+int frame(Engine* e) {
+    const Model& m = *e->m;
+    const int B = e->B;
+    TalkerSampleArgs sa;
+    sa.logits = e->wt.logits;
+    sa.V = m.cfg.talker_vocab;
+    sa.R = B;
+    sa.audio_vocab = m.cfg.cp_vocab;
+    sa.eos = m.cfg.codec_eos;
+    sa.past = e->d_past;
+    sa.n_past = e->d_npast;
+    sa.n_text = e->d_ntext;
+    sa.done = e->d_done;
+    sa.codes = e->d_codes;
+    sa.n_frames = e->d_nframes;
+    sa.frame_cap = e->max_frames;
+    sa.pos0 = e->d_pos0;
+    sa.pos = e->d_posdec;
+    sa.ignore_eos = e->ignore_eos;
+    sa.max_frames = e->cap_frames;
+    if (launch_talker_sample(e->s, sa)) return -1;
+    CpFrameIO io;
+    io.codes = e->d_codes;
+    io.n_frames = e->d_nframes;
+    io.frame_cap = e->max_frames;
+    io.fb_h = e->wt.h;
+    io.fb_ssq = e->wt.ssq;
+    io.pad_embed = e->d_pad;
+    if (cp_frame(e->s, m, e->wc, e->kv_c, B, io)) return -1;
+    RowMap rm;
+    rm.slot = e->d_iota;
+    rm.pos = e->d_posdec;
+    if (run_stack(e->s, m, m.talker, e->wt, e->kv_t, B, rm, 1024)) return -1;
+    return talker_tail(e, B, nullptr);
+}
+
+}  // namespace
+
+extern "C" {
+
+void q3e_free(void* ee) {
+    Engine* e = (Engine*)ee;
+    if (!e) return;
+    if (e->s) hipStreamSynchronize(e->s);
+    e->graph.reset();
+    kv_free(e->kv_t);
+    kv_free(e->kv_c);
+    work_free(e->wt);
+    work_free(e->wc);
+    void* ps[] = {e->d_slot, e->d_pos,  e->d_iota,   e->d_past,    e->d_npast, e->d_ntext, e->d_done,
+                  e->d_nframes, e->d_pos0, e->d_posdec, e->d_lastrow, e->d_codes, e->d_pad};
+    for (void* p : ps)
+        if (p) hipFree(p);
+    if (e->h_done) hipHostFree(e->h_done);
+    if (e->ev0) hipEventDestroy(e->ev0);
+    if (e->ev1) hipEventDestroy(e->ev1);
+    if (e->s) hipStreamDestroy(e->s);
+    if (e->m) model_free(e->m);
+    delete e;
+}
+
+void* q3e_create(const char* weights, int max_batch, int n_ctx, int max_frames) {
+    if (!weights || max_batch <= 0 || n_ctx <= 0 || max_frames <= 0) return nullptr;
+    Model* m = model_load(weights, true, true);
+    if (!m) return nullptr;
+    if (n_ctx > m->max_pos) {
+        Q3_LOG("q3e_create: n_ctx=%d exceeds the RoPE table (%d)", n_ctx, m->max_pos);
+        model_free(m);
+        return nullptr;
+    }
+    Engine* e = new Engine();
+    e->m = m;
+    e->max_batch = max_batch;
+    e->n_ctx = n_ctx;
+    e->max_frames = max_frames;
+    const ModelCfg& c = m->cfg;
+    e->prefill_rows = max_batch > 2048 ? max_batch : 2048;
+    bool ok = hipStreamCreate(&e->s) == hipSuccess;
+    ok = ok && hipEventCreate(&e->ev0) == hipSuccess && hipEventCreate(&e->ev1) == hipSuccess;
+    ok = ok && kv_alloc(e->kv_t, c.talker_layers, max_batch, c.n_kv, n_ctx) == 0;
+    ok = ok && kv_alloc(e->kv_c, c.cp_layers, max_batch, c.n_kv, c.cp_groups + 1) == 0;
+    ok = ok && work_alloc(e->wt, c, e->prefill_rows, c.talker_ffn, c.talker_vocab) == 0;
+    ok = ok && work_alloc(e->wc, c, max_batch, c.cp_ffn, c.cp_vocab) == 0;
+    auto ialloc = [&](int** p, size_t n) { return hipMalloc((void**)p, sizeof(int) * n) == hipSuccess; };
+    ok = ok && ialloc(&e->d_slot, e->prefill_rows) && ialloc(&e->d_pos, e->prefill_rows);
+    ok = ok && ialloc(&e->d_iota, max_batch) && ialloc(&e->d_past, (size_t)max_batch * 32);
+    ok = ok && ialloc(&e->d_npast, max_batch) && ialloc(&e->d_ntext, max_batch) && ialloc(&e->d_done, max_batch);
+    ok = ok && ialloc(&e->d_nframes, max_batch) && ialloc(&e->d_pos0, max_batch) && ialloc(&e->d_posdec, max_batch);
+    ok = ok && ialloc(&e->d_lastrow, max_batch);
+    ok = ok && ialloc(&e->d_codes, (size_t)max_frames * max_batch * 16);
+    ok = ok && hipMalloc((void**)&e->d_pad, sizeof(float) * c.hidden) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&e->h_done, sizeof(int) * max_batch, 0) == hipSuccess;
+    if (ok) {
+        std::vector<int> iota(max_batch);
+        for (int i = 0; i < max_batch; i++) iota[i] = i;
+        ok = hipMemcpy(e->d_iota, iota.data(), sizeof(int) * max_batch, hipMemcpyHostToDevice) == hipSuccess;
+        ok = ok && hipMemset(e->d_pad, 0, sizeof(float) * c.hidden) == hipSuccess;
+    }
+    if (!ok) {
+        Q3_LOG("q3e_create: allocation failed");
+        q3e_free(e);
+        return nullptr;
+    }
+    return e;
+}
+
+int q3e_set_pad_embed(void* ee, const float* pad) {
+    Engine* e = (Engine*)ee;
+    if (!e || !pad) return -1;
+    Q3_HIP(hipMemcpy(e->d_pad, pad, sizeof(float) * e->m->cfg.hidden, hipMemcpyHostToDevice), -1);
+    return 0;
+}
+
+int q3e_start(void* ee, int B, const float* prefix, const int32_t* n_rows, const int32_t* n_text, int ignore_eos,
+              int max_frames) {
+    Engine* e = (Engine*)ee;
+    if (!e || !prefix || !n_rows || !n_text || B <= 0 || B > e->max_batch) return -1;
+    const Model& m = *e->m;
+    const int H = m.cfg.hidden;
+    if (max_frames <= 0 || max_frames > e->max_frames) max_frames = e->max_frames;
+    std::vector<int> pos0(B), last(B);
+    for (int b = 0; b < B; b++) {
+        if (n_rows[b] <= 0 || n_rows[b] > e->prefill_rows || n_rows[b] + max_frames > e->n_ctx) {
+            Q3_LOG("q3e_start: utterance %d: %d prefix rows + %d frames do not fit n_ctx=%d", b, n_rows[b], max_frames,
+                   e->n_ctx);
+            return -1;
+        }
+        pos0[b] = n_rows[b];
+    }
+    e->B = B;
+    e->ignore_eos = ignore_eos ? 1 : 0;
+    e->cap_frames = max_frames;
+    e->frames_run = 0;
+    Q3_HIP(hipMemsetAsync(e->d_npast, 0, sizeof(int) * B, e->s), -1);
+    Q3_HIP(hipMemsetAsync(e->d_done, 0, sizeof(int) * B, e->s), -1);
+    Q3_HIP(hipMemsetAsync(e->d_nframes, 0, sizeof(int) * B, e->s), -1);
+    Q3_HIP(hipMemsetAsync(e->d_past, 0, sizeof(int) * 32 * B, e->s), -1);
+    Q3_HIP(hipMemsetAsync(e->d_codes, 0xff, sizeof(int) * 16 * (size_t)B * e->max_frames, e->s), -1);
+    Q3_HIP(hipMemcpyAsync(e->d_ntext, n_text, sizeof(int) * B, hipMemcpyHostToDevice, e->s), -1);
+    Q3_HIP(hipMemcpyAsync(e->d_pos0, pos0.data(), sizeof(int) * B, hipMemcpyHostToDevice, e->s), -1);
+    Q3_HIP(hipMemcpyAsync(e->d_posdec, pos0.data(), sizeof(int) * B, hipMemcpyHostToDevice, e->s), -1);
+    Q3_HIP(hipStreamSynchronize(e->s), -1);
+    Q3_HIP(hipEventRecord(e->ev0, e->s), -1);
+    // ragged prefill: utterances are packed into passes of at most prefill_rows rows; every row
+    // carries its own (slot, position).  Hidden of each utterance's last row lands in row b of
+    // the post-norm buffers, in utterance order, one group at a time.
+    size_t row_off = 0;
+    int b0 = 0;
+    std::vector<int> slot, pos;
+    while (b0 < B) {
+        int b1 = b0, rows = 0;
+        while (b1 < B && rows + n_rows[b1] <= e->prefill_rows) rows += n_rows[b1++];
+        slot.resize(rows);
+        pos.resize(rows);
+        int r = 0;
+        for (int b = b0; b < b1; b++) {
+            for (int i = 0; i < n_rows[b]; i++, r++) {
+                slot[r] = b;
+                pos[r] = i;
+            }
+            last[b] = r - 1;
+        }
+        Q3_HIP(hipMemcpyAsync(e->wt.h, prefix + row_off * H, sizeof(float) * (size_t)rows * H, hipMemcpyHostToDevice, e->s), -1);
+        Q3_HIP(hipMemcpyAsync(e->d_slot, slot.data(), sizeof(int) * rows, hipMemcpyHostToDevice, e->s), -1);
+        Q3_HIP(hipMemcpyAsync(e->d_pos, pos.data(), sizeof(int) * rows, hipMemcpyHostToDevice, e->s), -1);
+        Q3_HIP(hipMemcpyAsync(e->d_lastrow + b0, last.data() + b0, sizeof(int) * (b1 - b0), hipMemcpyHostToDevice, e->s), -1);
+        if (launch_ssq_rows(e->s, e->wt.h, e->wt.ssq, rows, H)) return -1;
+        RowMap rm;
+        rm.slot = e->d_slot;
+        rm.pos = e->d_pos;
+        rm.same_slot_rows = true;
+        if (run_stack(e->s, m, m.talker, e->wt, e->kv_t, rows, rm, 1024)) return -1;
+        // final norm of the last rows of this group into rows b0..b1 of the post-norm buffers
+        {
+            FinalNormArgs f;
+            f.h = e->wt.h;
+            f.ssq = e->wt.ssq;
+            f.ssq_parts = H / 16;
+            f.gamma = m.talker.final_norm;
+            f.eps = m.cfg.eps;
+            f.R = b1 - b0;
+            f.H = H;
+            f.row_map = e->d_lastrow + b0;
+            f.out_f32 = e->wt.hidden_f32 + (size_t)b0 * H;
+            f.out_f16 = e->wt.hidden_f16 + (size_t)b0 * H;
+            f.out_copy = e->wc.h + (size_t)b0 * H;
+            f.out_copy_ssq = e->wc.ssq + (size_t)b0 * (H / 16);
+            if (launch_final_norm(e->s, f)) return -1;
+        }
+        Q3_HIP(hipStreamSynchronize(e->s), -1);  // host staging vectors are reused by the next group
+        row_off += rows;
+        b0 = b1;
+    }
+    {
+        LinArgs a;
+        a.wp = m.talker_head.wp;
+        a.N = m.cfg.talker_vocab;
+        a.K = H;
+        a.M = B;
+        a.nt = 1;
+        a.x16 = e->wt.hidden_f16;
+        a.y = e->wt.logits;
+        a.ldy = m.cfg.talker_vocab;
+        if (launch_linear(e->s, a, PRO_F16, EPI_STORE)) return -1;
+    }
+    Q3_HIP(hipEventRecord(e->ev1, e->s), -1);
+    Q3_HIP(hipStreamSynchronize(e->s), -1);
+    hipEventElapsedTime(&e->last_prefill_ms, e->ev0, e->ev1);
+    return 0;
+}
+
+int q3e_run(void* ee, int n_frames) {
+    Engine* e = (Engine*)ee;
+    if (!e || e->B <= 0 || n_frames <= 0) return -1;
+    int done_frames = 0;
+    Q3_HIP(hipEventRecord(e->ev0, e->s), -1);
+    const bool need_capture = !e->graph.e || e->graph_B != e->B || e->graph_ignore != e->ignore_eos ||
+                              e->graph_cap != e->cap_frames;
+    if (need_capture) {
+        // first frame eagerly (real work; also sets the kernels' LDS attributes), then capture
+        if (frame(e)) return -1;
+        done_frames++;
+        Q3_HIP(hipStreamSynchronize(e->s), -1);
+        e->graph.reset();
+        Q3_HIP(hipStreamBeginCapture(e->s, hipStreamCaptureModeRelaxed), -1);
+        int rc = frame(e);
+        hipError_t er = hipStreamEndCapture(e->s, &e->graph.g);
+        if (rc || er != hipSuccess) {
+            Q3_LOG("q3e_run: graph capture failed");
+            return -1;
+        }
+        Q3_HIP(hipGraphInstantiate(&e->graph.e, e->graph.g, nullptr, nullptr, 0), -1);
+        e->graph_B = e->B;
+        e->graph_ignore = e->ignore_eos;
+        e->graph_cap = e->cap_frames;
+    }
+    const int check_every = 16;
+    while (done_frames < n_frames) {
+        int chunk = n_frames - done_frames;
+        if (!e->ignore_eos && chunk > check_every) chunk = check_every;
+        for (int i = 0; i < chunk; i++) Q3_HIP(hipGraphLaunch(e->graph.e, e->s), -1);
+        done_frames += chunk;
+        if (!e->ignore_eos && done_frames < n_frames) {
+            Q3_HIP(hipMemcpyAsync(e->h_done, e->d_done, sizeof(int) * e->B, hipMemcpyDeviceToHost, e->s), -1);
+            Q3_HIP(hipStreamSynchronize(e->s), -1);
+            bool all = true;
+            for (int b = 0; b < e->B; b++) all = all && e->h_done[b];
+            if (all) break;
+        }
+    }
+    Q3_HIP(hipEventRecord(e->ev1, e->s), -1);
+    Q3_HIP(hipStreamSynchronize(e->s), -1);
+    hipEventElapsedTime(&e->last_run_ms, e->ev0, e->ev1);
+    e->frames_run += done_frames;
+    return done_frames;
+}
+
+float q3e_last_run_ms(void* ee) { return ee ? ((Engine*)ee)->last_run_ms : -1.f; }
+float q3e_last_prefill_ms(void* ee) { return ee ? ((Engine*)ee)->last_prefill_ms : -1.f; }
+
+int q3e_get_codes(void* ee, int32_t* out, int max_out_frames, int32_t* n_frames_per_utt) {
+    Engine* e = (Engine*)ee;
+    if (!e || !out || e->B <= 0) return -1;
+    int nf = e->frames_run < e->max_frames ? e->frames_run : e->max_frames;
+    if (nf > max_out_frames) nf = max_out_frames;
+    Q3_HIP(hipMemcpy(out, e->d_codes, sizeof(int) * 16 * (size_t)e->B * nf, hipMemcpyDeviceToHost), -1);
+    if (n_frames_per_utt) {
+        Q3_HIP(hipMemcpy(n_frames_per_utt, e->d_npast, sizeof(int) * e->B, hipMemcpyDeviceToHost), -1);
+    }
+    return nf;
+}
+
+int q3e_get_hidden(void* ee, float* out) {
+    Engine* e = (Engine*)ee;
+    if (!e || !out || e->B <= 0) return -1;
+    Q3_HIP(hipMemcpy(out, e->wt.hidden_f32, sizeof(float) * (size_t)e->B * e->m->cfg.hidden, hipMemcpyDeviceToHost), -1);
+    return 0;
+}
+
+double q3e_step_weight_bytes(void* ee) {
+    Engine* e = (Engine*)ee;
+    if (!e) return 0.0;
+    const ModelCfg& c = e->m->cfg;
+    const double head = 2.0 * c.hidden;
+    return (double)e->m->talker.weight_bytes + head * c.talker_vocab +
+           (double)(c.cp_groups + 1) * (double)e->m->cp.weight_bytes + head * c.cp_vocab * c.cp_groups;
+}
+
+}  // extern "C"

@@ -137,3 +137,38 @@ float q3t_bench_linear(int M, int N, int K, int pro, int epi, int nt, int n_copi
 }
 
 }  // extern "C"
+
+// Talker sampling kernel on host arrays: logits[V], the chronological list of already emitted
+// code_0 (n_past entries), n_text.  Returns the emitted code, or -1 when the utterance ends
+// (EOS / non-audio id / forced EOS); -1000 on error.
+extern "C" int q3t_talker_sample(const float* logits, int V, const int* past, int n_past, int n_text, int ignore_eos) {
+    DBuf dl, dpast, dn, dnt, ddone, dcodes, dnf, dpos0, dpos;
+    int ring[32] = {0};
+    for (int i = n_past > 32 ? n_past - 32 : 0; i < n_past; i++) ring[i & 31] = past[i];
+    int zero = 0, pos0 = 7;
+    if (!dl.up(logits, (size_t)V * 4) || !dpast.up(ring, sizeof(ring)) || !dn.up(&n_past, 4) || !dnt.up(&n_text, 4) ||
+        !ddone.up(&zero, 4) || !dcodes.alloc(16 * 4) || !dnf.up(&zero, 4) || !dpos0.up(&pos0, 4) || !dpos.up(&zero, 4))
+        return -1000;
+    TalkerSampleArgs a;
+    a.logits = (const float*)dl.p;
+    a.V = V;
+    a.R = 1;
+    a.past = (int*)dpast.p;
+    a.n_past = (int*)dn.p;
+    a.n_text = (const int*)dnt.p;
+    a.done = (int*)ddone.p;
+    a.codes = (int*)dcodes.p;
+    a.n_frames = (int*)dnf.p;
+    a.frame_cap = 1;
+    a.pos0 = (const int*)dpos0.p;
+    a.pos = (int*)dpos.p;
+    a.ignore_eos = ignore_eos;
+    if (launch_talker_sample(nullptr, a)) return -1000;
+    int code = -1000;
+    if (hipDeviceSynchronize() != hipSuccess) return -1000;
+    if (hipMemcpy(&code, dcodes.p, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1000;
+    return code;
+}
+
+// Select the HIP device used by every handle created afterwards on this thread (one process per GPU).
+extern "C" int q3_set_device(int dev) { return hipSetDevice(dev) == hipSuccess ? 0 : -1; }

@@ -1,0 +1,73 @@
+"""Host side of the fused on-device frame loop (include/qwen3tts_engine.h).
+
+Stands where the reference's client closes the loop over sockets (dual_npu/tts_client.py:144-215);
+the per-frame work (talker step, 15-group code predictor, feedback sum) stays on the GPU."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import hiplib
+
+
+class FrameEngine:
+    def __init__(self, weights_path, max_batch=32, n_ctx=512, max_frames=256):
+        self._lib = hiplib.load()
+        self.h = self._lib.q3e_create(str(weights_path).encode(), max_batch, n_ctx, max_frames)
+        if not self.h:
+            raise RuntimeError(f"q3e_create failed: {weights_path}")
+        self.max_batch, self.n_ctx, self.max_frames = max_batch, n_ctx, max_frames
+        self.B = 0
+
+    def set_pad_embed(self, pad):
+        pad = np.ascontiguousarray(pad, dtype=np.float32).reshape(-1)
+        if self._lib.q3e_set_pad_embed(self.h, hiplib.fptr(pad)) != 0:
+            raise RuntimeError("q3e_set_pad_embed failed")
+
+    def start(self, prefixes, n_text, ignore_eos=False, max_frames=0):
+        """prefixes: list of [n_b, hidden] f32 prefix matrices (llamacpp_talker_server.py:121-161)."""
+        n_rows = np.array([p.shape[0] for p in prefixes], np.int32)
+        cat = np.ascontiguousarray(np.concatenate(prefixes, axis=0), dtype=np.float32)
+        nt = np.ascontiguousarray(n_text, dtype=np.int32)
+        self.B = len(prefixes)
+        rc = self._lib.q3e_start(self.h, self.B, hiplib.fptr(cat), hiplib.iptr(n_rows), hiplib.iptr(nt),
+                                 int(bool(ignore_eos)), int(max_frames))
+        if rc != 0:
+            raise RuntimeError(f"q3e_start failed: {rc}")
+
+    def run(self, n_frames):
+        rc = self._lib.q3e_run(self.h, int(n_frames))
+        if rc < 0:
+            raise RuntimeError(f"q3e_run failed: {rc}")
+        return rc
+
+    @property
+    def last_run_ms(self):
+        return float(self._lib.q3e_last_run_ms(self.h))
+
+    @property
+    def last_prefill_ms(self):
+        return float(self._lib.q3e_last_prefill_ms(self.h))
+
+    @property
+    def step_weight_bytes(self):
+        return float(self._lib.q3e_step_weight_bytes(self.h))
+
+    def codes(self):
+        """-> (codes[frames][B][16] int32, frames emitted per utterance)."""
+        out = np.full((self.max_frames, self.B, 16), -1, np.int32)
+        per = np.zeros(self.B, np.int32)
+        nf = self._lib.q3e_get_codes(self.h, hiplib.iptr(out), self.max_frames, hiplib.iptr(per))
+        if nf < 0:
+            raise RuntimeError("q3e_get_codes failed")
+        return out[:nf], per
+
+    def hidden(self):
+        out = np.empty((self.B, 1024), np.float32)
+        if self._lib.q3e_get_hidden(self.h, hiplib.fptr(out)) != 0:
+            raise RuntimeError("q3e_get_hidden failed")
+        return out
+
+    def destroy(self):
+        if self.h:
+            self._lib.q3e_free(self.h)
+            self.h = None

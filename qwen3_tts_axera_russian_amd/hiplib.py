@@ -57,11 +57,24 @@ def load(path: str | None = None):
     _sig(lib, "cp_predict_batch", c_int, [c_void_p, f32p, i32p, c_int, c_float, c_int, ctypes.c_uint64, i32p])
     _sig(lib, "cp_step", c_int, [c_void_p, f32p, c_int, f32p])
     _sig(lib, "cp_lm_head", c_int, [c_void_p, c_int, f32p, f32p])
+    # include/qwen3tts_engine.h
+    _sig(lib, "q3e_create", c_void_p, [c_char_p, c_int, c_int, c_int])
+    _sig(lib, "q3e_free", None, [c_void_p])
+    _sig(lib, "q3e_set_pad_embed", c_int, [c_void_p, f32p])
+    _sig(lib, "q3e_start", c_int, [c_void_p, c_int, f32p, i32p, i32p, c_int, c_int])
+    _sig(lib, "q3e_run", c_int, [c_void_p, c_int])
+    _sig(lib, "q3e_last_run_ms", c_float, [c_void_p])
+    _sig(lib, "q3e_last_prefill_ms", c_float, [c_void_p])
+    _sig(lib, "q3e_get_codes", c_int, [c_void_p, i32p, c_int, i32p])
+    _sig(lib, "q3e_get_hidden", c_int, [c_void_p, f32p])
+    _sig(lib, "q3e_step_weight_bytes", ctypes.c_double, [c_void_p])
     # test hooks
     _sig(lib, "q3t_device_count", c_int, [])
+    _sig(lib, "q3_set_device", c_int, [c_int])
     _sig(lib, "q3t_set_linear_tuning", c_int, [c_int, c_int])
     _sig(lib, "q3t_linear", c_int, [c_int, c_int, c_int, u16p, c_int, c_int, c_int, u16p, f32p, f32p, c_float,
                                     f32p, f32p, u16p, c_int])
+    _sig(lib, "q3t_talker_sample", c_int, [f32p, c_int, i32p, c_int, c_int, c_int])
     _sig(lib, "q3t_bench_linear", c_float, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int])
     if path is None:
         _lib = lib
