@@ -22,26 +22,21 @@ int cp_frame(hipStream_t s, const Model& m, Work& w, KVCache& kv, int R, const C
     for (int g = 0; g < G; g++) {
         rm.pos_base = g + 1;
         if (run_stack(s, m, m.cp, w, kv, R, rm, 256)) return -1;
-        FinalNormArgs f;
-        f.h = w.h;
-        f.ssq = w.ssq;
-        f.ssq_parts = H / 16;
-        f.gamma = m.cp.final_norm;
-        f.eps = c.eps;
-        f.R = R;
-        f.H = H;
-        f.out_f16 = w.hidden_f16;
-        if (launch_final_norm(s, f)) return -1;
+        // final RMSNorm folded into the head GEMV's prologue (code_predictor_server.py:129,136)
         LinArgs a;
         a.wp = m.cp_head[g].wp;
         a.N = c.cp_vocab;
         a.K = H;
         a.M = R;
         a.nt = 0;
-        a.x16 = w.hidden_f16;
+        a.h = w.h;
+        a.ssq = w.ssq;
+        a.ssq_parts = H / 16;
+        a.gamma = m.cp.final_norm;
+        a.eps = c.eps;
         a.y = w.logits;
         a.ldy = c.cp_vocab;
-        if (launch_linear(s, a, PRO_F16, EPI_STORE)) return -1;
+        if (launch_linear(s, a, PRO_NORM, EPI_STORE)) return -1;
         CpArgmaxArgs x;
         x.logits = w.logits;
         x.V = c.cp_vocab;

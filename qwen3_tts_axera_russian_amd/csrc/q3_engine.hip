@@ -280,6 +280,17 @@ int q3e_run(void* ee, int n_frames) {
     if (!e || e->B <= 0 || n_frames <= 0) return -1;
     int done_frames = 0;
     Q3_HIP(hipEventRecord(e->ev0, e->s), -1);
+    // Q3_NO_GRAPH=1: eager launches (rocprofv3 --kernel-trace crashes on the 575-node graph replay)
+    static const bool no_graph = getenv("Q3_NO_GRAPH") && atoi(getenv("Q3_NO_GRAPH")) != 0;
+    if (no_graph) {
+        for (; done_frames < n_frames; done_frames++)
+            if (frame(e)) return -1;
+        Q3_HIP(hipEventRecord(e->ev1, e->s), -1);
+        Q3_HIP(hipStreamSynchronize(e->s), -1);
+        hipEventElapsedTime(&e->last_run_ms, e->ev0, e->ev1);
+        e->frames_run += done_frames;
+        return done_frames;
+    }
     const bool need_capture = !e->graph.e || e->graph_B != e->B || e->graph_ignore != e->ignore_eos ||
                               e->graph_cap != e->cap_frames;
     if (need_capture) {

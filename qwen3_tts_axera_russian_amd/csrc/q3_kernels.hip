@@ -83,6 +83,9 @@ template <int NB16, int MT16, int KBW, int NW, int PRO, int EPI, bool NT>
 __global__ void __launch_bounds__(NW * 64) linear_kernel(LinArgs a) {
     constexpr int MR = MT16 * 16, NB = NB16 * 16, NBP = NB + 4, KB = NW * KBW, K = KB * 32;
     constexpr int NTH = NW * 64;
+    constexpr int NOUT = (EPI == EPI_SWIGLU) ? MR * NB / 2 : MR * NB;   // outputs of this workgroup
+    constexpr int OPT = (NOUT + NTH - 1) / NTH;                         // outputs per thread
+    constexpr int SQI = (MR * 16 + NTH - 1) / NTH;                      // ssq float4 groups per thread
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int q = lane >> 4, c = lane & 15;
     const int tile0 = blockIdx.x * NB16;
@@ -91,7 +94,57 @@ __global__ void __launch_bounds__(NW * 64) linear_kernel(LinArgs a) {
     float* red = (float*)smem;             // [NW][MR][NBP]
     float* inv_s = red + NW * MR * NBP;    // [MR]
 
-    // 1. the weight stream: everything this wave will need, in flight at once
+    // ---- 1. every global load of the kernel is issued here, activation-side first ----
+    // vmcnt retires in order: the small L2-resident operands must not queue behind the HBM weight
+    // stream, and nothing later in the kernel starts a second memory round trip.
+    float4 sq[SQI];
+    float4 hraw[MT16][KBW][2];
+    float4 graw[KBW][2];
+    h8 af[MT16][KBW];
+    float hold[OPT];
+    if (PRO == PRO_NORM) {
+#pragma unroll
+        for (int i = 0; i < SQI; i++) {
+            const int g4 = tid + i * NTH;          // float4 group: row = g4/16 (64 partials = 16 float4)
+            const int m = m0 + g4 / 16;
+            sq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g4 < MR * 16 && m < a.M) sq[i] = *(const float4*)(a.ssq + (size_t)m * 64 + (g4 & 15) * 4);
+        }
+#pragma unroll
+        for (int kbi = 0; kbi < KBW; kbi++) {
+            const int k0 = (w * KBW + kbi) * 32 + q * 8;
+            graw[kbi][0] = *(const float4*)(a.gamma + k0);
+            graw[kbi][1] = *(const float4*)(a.gamma + k0 + 4);
+#pragma unroll
+            for (int mt = 0; mt < MT16; mt++) {
+                int m = m0 + mt * 16 + c;
+                if (m >= a.M) m = a.M - 1;  // padded rows recompute a valid row; never stored
+                hraw[mt][kbi][0] = *(const float4*)(a.h + (size_t)m * K + k0);
+                hraw[mt][kbi][1] = *(const float4*)(a.h + (size_t)m * K + k0 + 4);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int kbi = 0; kbi < KBW; kbi++) {
+            const int k0 = (w * KBW + kbi) * 32 + q * 8;
+#pragma unroll
+            for (int mt = 0; mt < MT16; mt++) {
+                int m = m0 + mt * 16 + c;
+                if (m >= a.M) m = a.M - 1;
+                af[mt][kbi] = *(const h8*)(a.x16 + (size_t)m * K + k0);
+            }
+        }
+    }
+    if (EPI == EPI_RESID) {
+#pragma unroll
+        for (int i = 0; i < OPT; i++) {
+            const int o = tid + i * NTH;
+            const int m = m0 + o / NB;
+            hold[i] = 0.f;
+            if (o < NOUT && m < a.M) hold[i] = a.h_out[(size_t)m * a.N + tile0 * 16 + (o % NB)];
+        }
+    }
+    // the weight stream: everything this wave will need, in flight at once
     h8 wf[NB16][KBW];
 #pragma unroll
     for (int nb = 0; nb < NB16; nb++)
@@ -100,46 +153,28 @@ __global__ void __launch_bounds__(NW * 64) linear_kernel(LinArgs a) {
             const h8* p = (const h8*)(a.wp + (((size_t)(tile0 + nb) * KB + (size_t)w * KBW + kbi) * 64 + lane) * 8);
             wf[nb][kbi] = NT ? __builtin_nontemporal_load(p) : *p;
         }
-    // keep the whole weight slab in flight before anything else is scheduled (one HBM round trip)
     __builtin_amdgcn_sched_barrier(0);
 
-    // 2. RMSNorm scale per row from the producer's sum-of-squares partials
+    // ---- 2. RMSNorm scale per row from the producer's 64 sum-of-squares partials (a.ssq_parts == 64) ----
     if (PRO == PRO_NORM) {
-        for (int mr = w; mr < MR; mr += NW) {
-            int m = m0 + mr;
-            float s = 0.f;
-            if (m < a.M)
-                for (int p = lane; p < a.ssq_parts; p += 64) s += a.ssq[(size_t)m * a.ssq_parts + p];
-            s = wave_sum(s);
-            if (lane == 0) inv_s[mr] = (m < a.M) ? 1.0f / sqrtf(s / (float)K + a.eps) : 0.f;
+#pragma unroll
+        for (int i = 0; i < SQI; i++) {
+            const int g4 = tid + i * NTH;
+            float s = (sq[i].x + sq[i].y) + (sq[i].z + sq[i].w);
+            s += __shfl_xor(s, 8, 16);
+            s += __shfl_xor(s, 4, 16);
+            s += __shfl_xor(s, 2, 16);
+            s += __shfl_xor(s, 1, 16);
+            if (g4 < MR * 16 && (g4 & 15) == 0) inv_s[g4 / 16] = 1.0f / sqrtf(s / (float)K + a.eps);
         }
         __syncthreads();
-    }
-
-    // 3. MFMA over this wave's K slice
-    f4 acc[MT16][NB16];
 #pragma unroll
-    for (int mt = 0; mt < MT16; mt++)
+        for (int kbi = 0; kbi < KBW; kbi++)
 #pragma unroll
-        for (int nb = 0; nb < NB16; nb++) acc[mt][nb] = (f4){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-    for (int kbi = 0; kbi < KBW; kbi++) {
-        const int k0 = (w * KBW + kbi) * 32 + q * 8;
-        h8 af[MT16];
-#pragma unroll
-        for (int mt = 0; mt < MT16; mt++) {
-            const int mr = mt * 16 + c;
-            int m = m0 + mr;
-            if (m >= a.M) m = a.M - 1;  // padded rows recompute a valid row; never stored
-            if (PRO == PRO_F16) {
-                af[mt] = *(const h8*)(a.x16 + (size_t)m * K + k0);
-            } else {
-                const float4 h0 = *(const float4*)(a.h + (size_t)m * K + k0);
-                const float4 h1 = *(const float4*)(a.h + (size_t)m * K + k0 + 4);
-                const float4 g0 = *(const float4*)(a.gamma + k0);
-                const float4 g1 = *(const float4*)(a.gamma + k0 + 4);
-                const float iv = inv_s[mr];
+            for (int mt = 0; mt < MT16; mt++) {
+                const float iv = inv_s[mt * 16 + c];
+                const float4 h0 = hraw[mt][kbi][0], h1 = hraw[mt][kbi][1];
+                const float4 g0 = graw[kbi][0], g1 = graw[kbi][1];
                 h8 t;
                 t[0] = sat_half((h0.x * iv) * g0.x);
                 t[1] = sat_half((h0.y * iv) * g0.y);
@@ -149,17 +184,25 @@ __global__ void __launch_bounds__(NW * 64) linear_kernel(LinArgs a) {
                 t[5] = sat_half((h1.y * iv) * g1.y);
                 t[6] = sat_half((h1.z * iv) * g1.z);
                 t[7] = sat_half((h1.w * iv) * g1.w);
-                af[mt] = t;
+                af[mt][kbi] = t;
             }
-        }
+    }
+
+    // ---- 3. MFMA over this wave's K slice ----
+    f4 acc[MT16][NB16];
+#pragma unroll
+    for (int mt = 0; mt < MT16; mt++)
+#pragma unroll
+        for (int nb = 0; nb < NB16; nb++) acc[mt][nb] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kbi = 0; kbi < KBW; kbi++)
 #pragma unroll
         for (int mt = 0; mt < MT16; mt++)
 #pragma unroll
             for (int nb = 0; nb < NB16; nb++)
-                acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], wf[nb][kbi], acc[mt][nb], 0, 0, 0);
-    }
+                acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][kbi], wf[nb][kbi], acc[mt][nb], 0, 0, 0);
 
-    // 4. partial tiles -> LDS.  D layout: col = lane&15, row = 4*(lane>>4) + reg.
+    // ---- 4. partial tiles -> LDS.  D layout: col = lane&15, row = 4*(lane>>4) + reg. ----
 #pragma unroll
     for (int mt = 0; mt < MT16; mt++)
 #pragma unroll
@@ -169,47 +212,52 @@ __global__ void __launch_bounds__(NW * 64) linear_kernel(LinArgs a) {
                 red[(w * MR + mt * 16 + 4 * q + r) * NBP + nb * 16 + c] = acc[mt][nb][r];
     __syncthreads();
 
-    // 5. fixed-order sum over waves + epilogue
+    // ---- 5. fixed-order sum over waves + epilogue ----
     if (EPI == EPI_STORE || EPI == EPI_RESID) {
-        for (int o = tid; o < MR * NB; o += NTH) {
-            const int mr = o / NB, n = o % NB;
-            float v = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < NW; ww++) v += red[(ww * MR + mr) * NBP + n];
-            const int m = m0 + mr;
-            const int ng = tile0 * 16 + n;
-            const bool ok = m < a.M;
-            if (EPI == EPI_STORE) {
-                if (ok) a.y[(size_t)m * a.ldy + ng] = v;
-            } else {
-                float hn = 0.f;
-                if (ok) {
-                    hn = a.h_out[(size_t)m * a.N + ng] + v;
-                    a.h_out[(size_t)m * a.N + ng] = hn;
+        for (int i = 0; i < OPT; i++) {
+            const int o = tid + i * NTH;
+            if (o < NOUT) {   // wave-uniform (NOUT and NTH are multiples of 64)
+                const int mr = o / NB, n = o % NB;
+                float v = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < NW; ww++) v += red[(ww * MR + mr) * NBP + n];
+                const int m = m0 + mr;
+                const int ng = tile0 * 16 + n;
+                const bool ok = m < a.M;
+                if (EPI == EPI_STORE) {
+                    if (ok) a.y[(size_t)m * a.ldy + ng] = v;
+                } else {
+                    const float hn = ok ? hold[i] + v : 0.f;
+                    if (ok) a.h_out[(size_t)m * a.N + ng] = hn;
+                    float s = hn * hn;
+                    s += __shfl_xor(s, 8, 16);
+                    s += __shfl_xor(s, 4, 16);
+                    s += __shfl_xor(s, 2, 16);
+                    s += __shfl_xor(s, 1, 16);
+                    if (ok && (n & 15) == 0) a.ssq_out[(size_t)m * (a.N / 16) + (ng >> 4)] = s;
                 }
-                float s = hn * hn;
-                s += __shfl_xor(s, 8, 16);
-                s += __shfl_xor(s, 4, 16);
-                s += __shfl_xor(s, 2, 16);
-                s += __shfl_xor(s, 1, 16);
-                if (ok && (n & 15) == 0) a.ssq_out[(size_t)m * (a.N / 16) + (ng >> 4)] = s;
             }
         }
     } else {  // EPI_SWIGLU: tile 2i = gate rows, tile 2i+1 = the matching up rows
         constexpr int NH = NB / 2;
-        for (int o = tid; o < MR * NH; o += NTH) {
-            const int mr = o / NH, j = o % NH;
-            const int i = j >> 4, cc = j & 15;
-            float g = 0.f, u = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < NW; ww++) {
-                g += red[(ww * MR + mr) * NBP + (2 * i) * 16 + cc];
-                u += red[(ww * MR + mr) * NBP + (2 * i + 1) * 16 + cc];
-            }
-            const int m = m0 + mr;
-            if (m < a.M) {
-                const float sg = g / (1.0f + expf(-g));
-                a.act[(size_t)m * (a.N / 2) + (size_t)blockIdx.x * NH + j] = sat_half(sg * u);
+        for (int i = 0; i < OPT; i++) {
+            const int o = tid + i * NTH;
+            if (o < NOUT) {
+                const int mr = o / NH, j = o % NH;
+                const int ii = j >> 4, cc = j & 15;
+                float g = 0.f, u = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < NW; ww++) {
+                    g += red[(ww * MR + mr) * NBP + (2 * ii) * 16 + cc];
+                    u += red[(ww * MR + mr) * NBP + (2 * ii + 1) * 16 + cc];
+                }
+                const int m = m0 + mr;
+                if (m < a.M) {
+                    const float sg = g / (1.0f + expf(-g));
+                    a.act[(size_t)m * (a.N / 2) + (size_t)blockIdx.x * NH + j] = sat_half(sg * u);
+                }
             }
         }
     }
@@ -239,11 +287,13 @@ static int launch_linear_t(hipStream_t s, const LinArgs& a) {
 }
 
 // (KBW, NW) per K; overridable for tuning through q3_set_linear_tuning().
-static int g_tune_kbw[3] = {8, 8, 6};  // K = 1024, 2048, 3072
-int set_linear_tuning(int K, int kbw) {
+// k-blocks per wave by [K = 1024, 2048, 3072][rows <= 16, <= 32, more]
+static int g_tune_kbw[3][3] = {{8, 4, 4}, {8, 8, 8}, {6, 6, 6}};
+int set_linear_tuning(int K, int mt16, int kbw) {
     int i = K == 1024 ? 0 : K == 2048 ? 1 : K == 3072 ? 2 : -1;
-    if (i < 0) return -1;
-    g_tune_kbw[i] = kbw;
+    int j = mt16 == 1 ? 0 : mt16 == 2 ? 1 : mt16 == 4 ? 2 : -1;
+    if (i < 0 || j < 0) return -1;
+    g_tune_kbw[i][j] = kbw;
     return 0;
 }
 
@@ -264,9 +314,9 @@ int launch_linear(hipStream_t s, const LinArgs& a, int pro, int epi) {
         Q3_LOG("launch_linear: unsupported shape N=%d K=%d", a.N, K);
         return -1;
     }
-    const int kbw = g_tune_kbw[ki];
-    const int nw = K / 32 / kbw;
     const int mt16 = a.M <= 16 ? 1 : a.M <= 32 ? 2 : 4;
+    const int kbw = g_tune_kbw[ki][mt16 == 1 ? 0 : mt16 == 2 ? 1 : 2];
+    const int nw = K / 32 / kbw;
     const int nb16 = (epi == EPI_SWIGLU) ? 2 : 1;
     // K = 1024
     Q3_LIN_MT(1, 8, 4, PRO_NORM, EPI_STORE)
@@ -280,7 +330,6 @@ int launch_linear(hipStream_t s, const LinArgs& a, int pro, int epi) {
     Q3_LIN_MT(1, 4, 16, PRO_F16, EPI_RESID)
     // K = 3072
     Q3_LIN_MT(1, 6, 16, PRO_F16, EPI_RESID)
-    Q3_LIN_MT(1, 8, 12, PRO_F16, EPI_RESID)
     Q3_LOG("launch_linear: no instantiation for K=%d kbw=%d nw=%d mt16=%d nb16=%d pro=%d epi=%d", K, kbw, nw,
            mt16, nb16, pro, epi);
     return -1;
@@ -412,22 +461,53 @@ __global__ void __launch_bounds__(1024) attn_kernel(AttnArgs a) {
     float* pv = dyn + 2 * (size_t)a.n_ctx; // [nwv][2][D]
     float* row = a.qkv + (size_t)r * a.ld;
     const size_t cbase = ((size_t)slot * a.n_kv + g) * (size_t)a.n_ctx * D;
+    const int T = (MODE == ATTN_FUSED) ? pos : pos + 1;  // rows read from the cache
+    const int l16 = tid & 15, grp = tid >> 4, ngrp = blockDim.x >> 4;
+    const half_t* kbase = a.kc + cbase;
+    const half_t* vbase = a.vc + cbase;
+
+    // ---- phase A loads first (they are consumed first; vmcnt retires in order), then the first
+    // APRE cached K and V rows of every 16-lane group: one memory round trip covers T <= APRE*ngrp ----
+    float x0 = 0.f, x1 = 0.f, gm0 = 1.f, gm1 = 1.f, cs = 1.f, sn = 0.f;
+    if (MODE != ATTN_ATTEND && w < 4) {
+        // wave 0,1: q heads 2g, 2g+1; wave 2: k head g; wave 3: v head g
+        const float* src = w < 2 ? row + (size_t)(2 * g + w) * D
+                         : w == 2 ? row + (size_t)(a.n_heads + g) * D
+                                  : row + (size_t)(a.n_heads + a.n_kv + g) * D;
+        x0 = src[lane];
+        x1 = src[lane + 64];
+        if (w < 3) {
+            const float* gam = w < 2 ? a.q_norm : a.k_norm;
+            gm0 = gam[lane];
+            gm1 = gam[lane + 64];
+            cs = a.rope_cos[(size_t)pos * 64 + lane];
+            sn = a.rope_sin[(size_t)pos * 64 + lane];
+        }
+    }
+    float qpre = 0.f;
+    if (MODE == ATTN_ATTEND && tid < 2 * D) qpre = row[(size_t)(2 * g) * D + tid];
+    constexpr int APRE = 4;
+    h8 kpre[APRE], vpre[APRE];
+    if (MODE != ATTN_PREP) {
+#pragma unroll
+        for (int i = 0; i < APRE; i++) {
+            const int t = grp + i * ngrp;
+            if (t < T) {
+                kpre[i] = *(const h8*)(kbase + (size_t)t * D + l16 * 8);
+                vpre[i] = *(const h8*)(vbase + (size_t)t * D + l16 * 8);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- phase A: per-head RMSNorm + RoPE (rotate-half pairs i, i+64) ----
     if (MODE != ATTN_ATTEND) {
         if (w < 4) {
-            // wave 0,1: q heads 2g, 2g+1; wave 2: k head g; wave 3: v head g
-            const float* src = w < 2 ? row + (size_t)(2 * g + w) * D
-                             : w == 2 ? row + (size_t)(a.n_heads + g) * D
-                                      : row + (size_t)(a.n_heads + a.n_kv + g) * D;
-            float x0 = src[lane], x1 = src[lane + 64];
             if (w < 3) {
-                const float* gam = w < 2 ? a.q_norm : a.k_norm;
                 float ss = wave_sum(x0 * x0 + x1 * x1);
                 const float iv = 1.0f / sqrtf(ss / (float)D + a.eps);
-                x0 = (x0 * iv) * gam[lane];
-                x1 = (x1 * iv) * gam[lane + 64];
-                const float cs = a.rope_cos[(size_t)pos * 64 + lane], sn = a.rope_sin[(size_t)pos * 64 + lane];
+                x0 = (x0 * iv) * gm0;
+                x1 = (x1 * iv) * gm1;
                 const float y0 = x0 * cs - x1 * sn;
                 const float y1 = x1 * cs + x0 * sn;
                 x0 = y0;
@@ -454,24 +534,42 @@ __global__ void __launch_bounds__(1024) attn_kernel(AttnArgs a) {
         }
         if (MODE == ATTN_PREP) return;
     } else {
-        if (tid < 2 * D) qs[tid / D][tid % D] = row[(size_t)(2 * g) * D + tid];
+        if (tid < 2 * D) qs[tid / D][tid % D] = qpre;
     }
     __syncthreads();
 
     // ---- phase B: scores.  16 lanes per cached row (16 B each), 4 rows per wave step ----
-    const int T = (MODE == ATTN_FUSED) ? pos : pos + 1;  // rows read from the cache
     const int ntot = pos + 1;
-    const int l16 = tid & 15, grp = tid >> 4, ngrp = blockDim.x >> 4;
     float q0[8], q1[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         q0[j] = qs[0][l16 * 8 + j];
         q1[j] = qs[1][l16 * 8 + j];
     }
-    const half_t* kbase = a.kc + cbase;
-    const half_t* vbase = a.vc + cbase;
+#pragma unroll
+    for (int i = 0; i < APRE; i++) {
+        const int t = grp + i * ngrp;
+        if (t < T) {
+            float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float kf = (float)kpre[i][j];
+                d0 += q0[j] * kf;
+                d1 += q1[j] * kf;
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                d0 += __shfl_xor(d0, o, 16);
+                d1 += __shfl_xor(d1, o, 16);
+            }
+            if (l16 == 0) {
+                sc[t] = d0 * a.scale;
+                sc[a.n_ctx + t] = d1 * a.scale;
+            }
+        }
+    }
 #pragma unroll 4
-    for (int t = grp; t < T; t += ngrp) {
+    for (int t = grp + APRE * ngrp; t < T; t += ngrp) {
         const h8 kk = *(const h8*)(kbase + (size_t)t * D + l16 * 8);
         float d0 = 0.f, d1 = 0.f;
 #pragma unroll
@@ -556,8 +654,21 @@ __global__ void __launch_bounds__(1024) attn_kernel(AttnArgs a) {
     float a0[8], a1[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) a0[j] = a1[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < APRE; i++) {
+        const int t = grp + i * ngrp;
+        if (t < T) {
+            const float p0 = sc[t], p1 = sc[a.n_ctx + t];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float vf = (float)vpre[i][j];
+                a0[j] += p0 * vf;
+                a1[j] += p1 * vf;
+            }
+        }
+    }
 #pragma unroll 4
-    for (int t = grp; t < T; t += ngrp) {
+    for (int t = grp + APRE * ngrp; t < T; t += ngrp) {
         const h8 vv = *(const h8*)(vbase + (size_t)t * D + l16 * 8);
         const float p0 = sc[t], p1 = sc[a.n_ctx + t];
 #pragma unroll
@@ -607,7 +718,10 @@ int launch_attn(hipStream_t s, const AttnArgs& a, int mode) {
         Q3_LOG("attn: only GQA group 2 (16q/8kv) is built, got %d/%d", a.n_heads, a.n_kv);
         return -1;
     }
+    // keep the launch small: ~64K threads fill in ~2 us, every further 64K cost ~1 us of ramp
     int threads = a.threads;
+    const int fit = 65536 / (a.R * a.n_kv);
+    if (threads > fit) threads = fit / 64 * 64;
     if (threads < 256) threads = 256;
     if (threads > 1024) threads = 1024;
     const size_t lds = ((size_t)2 * a.n_ctx + (size_t)(threads / 64) * 2 * 128) * sizeof(float);

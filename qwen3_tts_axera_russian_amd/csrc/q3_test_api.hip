@@ -4,7 +4,7 @@
 using namespace q3;
 
 namespace q3 {
-int set_linear_tuning(int K, int kbw);
+int set_linear_tuning(int K, int mt16, int kbw);
 }
 
 namespace {
@@ -26,7 +26,7 @@ int q3t_device_count(void) {
     return n;
 }
 
-int q3t_set_linear_tuning(int K, int kbw) { return set_linear_tuning(K, kbw); }
+int q3t_set_linear_tuning(int K, int mt16, int kbw) { return set_linear_tuning(K, mt16, kbw); }
 
 // One linear launch.  W is row-major fp16 [N][K]; gateup != 0 means rows [0,N/2) are gate and
 // [N/2,N) up (tile-interleaved on the device like the model loader does).
@@ -172,3 +172,69 @@ extern "C" int q3t_talker_sample(const float* logits, int V, const int* past, in
 
 // Select the HIP device used by every handle created afterwards on this thread (one process per GPU).
 extern "C" int q3_set_device(int dev) { return hipSetDevice(dev) == hipSuccess ? 0 : -1; }
+
+// ---- launch-boundary microbenchmark: a dependent chain of n small kernels, captured as a graph ----
+namespace {
+__global__ void chain_empty_kernel(float* buf) { (void)buf; }
+// every thread reads what the previous kernel wrote (another workgroup's element) and writes its own
+__global__ void chain_dep_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int hops) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = (i * 97 + 13) % n;
+    float v = in[j];
+    for (int h = 1; h < hops; h++) {  // extra dependent round trips
+        j = ((int)(v * 0.f) + j * 31 + 7) % n;
+        v += in[j];
+    }
+    out[i] = v + 1.0f;
+}
+}  // namespace
+
+// kind 0: empty kernels; kind >=1: `kind` dependent global round trips per kernel.
+// Returns average microseconds per kernel over `iters` graph replays of an n-kernel chain.
+extern "C" float q3t_bench_chain(int kind, int blocks, int threads, int n_kernels, int iters, int use_graph) {
+    hipStream_t s = nullptr;
+    if (hipStreamCreate(&s) != hipSuccess) return -1.f;
+    const int n = blocks * threads;
+    DBuf a, b;
+    if (!a.alloc((size_t)n * 4) || !b.alloc((size_t)n * 4)) return -1.f;
+    hipMemset(a.p, 0, (size_t)n * 4);
+    hipMemset(b.p, 0, (size_t)n * 4);
+    auto chain = [&]() {
+        for (int k = 0; k < n_kernels; k++) {
+            float* in = (float*)((k & 1) ? b.p : a.p);
+            float* out = (float*)((k & 1) ? a.p : b.p);
+            if (kind == 0) hipLaunchKernelGGL(chain_empty_kernel, dim3(blocks), dim3(threads), 0, s, out);
+            else hipLaunchKernelGGL(chain_dep_kernel, dim3(blocks), dim3(threads), 0, s, in, out, n, kind);
+        }
+    };
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    chain();
+    hipStreamSynchronize(s);
+    if (use_graph) {
+        hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
+        chain();
+        if (hipStreamEndCapture(s, &g) != hipSuccess) return -1.f;
+        if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) return -1.f;
+        hipGraphLaunch(ge, s);
+        hipStreamSynchronize(s);
+    }
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventRecord(e0, s);
+    for (int it = 0; it < iters; it++) {
+        if (use_graph) hipGraphLaunch(ge, s);
+        else chain();
+    }
+    hipEventRecord(e1, s);
+    hipStreamSynchronize(s);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (ge) hipGraphExecDestroy(ge);
+    if (g) hipGraphDestroy(g);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipStreamDestroy(s);
+    return ms * 1000.f / ((float)iters * n_kernels);
+}

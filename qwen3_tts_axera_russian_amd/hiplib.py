@@ -71,7 +71,7 @@ def load(path: str | None = None):
     # test hooks
     _sig(lib, "q3t_device_count", c_int, [])
     _sig(lib, "q3_set_device", c_int, [c_int])
-    _sig(lib, "q3t_set_linear_tuning", c_int, [c_int, c_int])
+    _sig(lib, "q3t_set_linear_tuning", c_int, [c_int, c_int, c_int])
     _sig(lib, "q3t_linear", c_int, [c_int, c_int, c_int, u16p, c_int, c_int, c_int, u16p, f32p, f32p, c_float,
                                     f32p, f32p, u16p, c_int])
     _sig(lib, "q3t_talker_sample", c_int, [f32p, c_int, i32p, c_int, c_int, c_int])
