@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (config 3/4: 32)")
     ap.add_argument("--frames", type=int, default=64, help="frames per utterance per step (one vocoder chunk)")
+    ap.add_argument("--chains", type=int, default=0, help="parallel row groups per frame (0 = engine default)")
     ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 latency leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-frames", type=int, default=12)
@@ -154,6 +155,8 @@ def main():
     prefixes, n_text, pad = workload(B, rank, a.seed)
     n_ctx = max(p.shape[0] for p in prefixes) + F + 8
     eng = FrameEngine(path, max_batch=B, n_ctx=n_ctx, max_frames=F)
+    if a.chains > 0:
+        eng.set_chains(a.chains)
     dt, frame_ms, prefill_ms = run_leg(eng, prefixes, n_text, pad, F, a.steps, a.warmup, sync_all)
     step_w_bytes = eng.step_weight_bytes
     if dist is not None:

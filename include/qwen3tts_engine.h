@@ -26,6 +26,11 @@ extern "C" {
 void* q3e_create(const char* weights, int max_batch, int n_ctx, int max_frames);
 void q3e_free(void* e);
 
+/* Split every frame step into n (1..8) independent row groups that run as parallel branches of the
+ * captured graph: hides per-kernel launch latency behind the other groups' work at the price of
+ * streaming the weights n times.  Default: 2 when max_batch >= 16, else 1 (env Q3_CHAINS overrides). */
+int q3e_set_chains(void* e, int n);
+
 /* tts_pad embedding added to every feedback (tts_client.py:207-208); zeros until set. */
 int q3e_set_pad_embed(void* e, const float* pad_embed /*[hidden]*/);
 

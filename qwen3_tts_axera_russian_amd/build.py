@@ -29,21 +29,23 @@ def _newer(dst: str, srcs) -> bool:
     return all(os.path.getmtime(s) <= t for s in srcs)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, timeline: bool = False) -> str:
+    """timeline=True builds lib/libqwen3tts_tl.so with in-kernel time stamps (diagnostics only)."""
     os.makedirs(LIB, exist_ok=True)
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs += [os.path.join(HERE, "..", "include", f) for f in os.listdir(os.path.join(HERE, "..", "include"))]
-    out = os.path.join(LIB, "libqwen3tts.so")
+    tag = "_tl" if timeline else ""
+    out = os.path.join(LIB, f"libqwen3tts{tag}.so")
     objs = []
     for s in srcs:
-        o = os.path.join(LIB, os.path.basename(s) + ".o")
+        o = os.path.join(LIB, os.path.basename(s) + tag + ".o")
         objs.append(o)
         if not force and _newer(o, [s] + hdrs):
             continue
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", s, "-o", o,
-               "-Wno-unused-result", "-Wno-unused-value", "-Wno-pass-failed"]
+               "-Wno-unused-result", "-Wno-unused-value", "-Wno-pass-failed"] + (["-DQ3_TIMELINE"] if timeline else [])
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -52,11 +54,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    alias = os.path.join(LIB, "llama_wrapper.so")
-    if not os.path.exists(alias) or os.path.getmtime(alias) < os.path.getmtime(out):
-        shutil.copyfile(out, alias)
+    if not timeline:
+        alias = os.path.join(LIB, "llama_wrapper.so")
+        if not os.path.exists(alias) or os.path.getmtime(alias) < os.path.getmtime(out):
+            shutil.copyfile(out, alias)
     return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, timeline="--timeline" in sys.argv))

@@ -15,7 +15,8 @@ struct CpFrameIO {
 };
 
 // w.h / w.ssq hold the talker hidden of each row (position 0 input).  Runs positions 0..n_groups,
-// writes columns 1..n_groups of each row's frame.
-int cp_frame(hipStream_t s, const Model& m, Work& w, KVCache& kv, int R, const CpFrameIO& io);
+// writes columns 1..n_groups of each row's frame.  Rows row0..row0+R-1 of a batch of R_total rows.
+int cp_frame(hipStream_t s, const Model& m, Work& w, KVCache& kv, int R, const CpFrameIO& io, int row0 = 0,
+             int R_total = 0);
 
 }  // namespace q3

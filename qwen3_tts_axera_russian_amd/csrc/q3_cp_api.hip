@@ -6,8 +6,9 @@
 
 namespace q3 {
 
-int cp_frame(hipStream_t s, const Model& m, Work& w, KVCache& kv, int R, const CpFrameIO& io) {
+int cp_frame(hipStream_t s, const Model& m, Work& w, KVCache& kv, int R, const CpFrameIO& io, int row0, int R_total) {
     const ModelCfg& c = m.cfg;
+    if (R_total <= 0) R_total = R;
     const int H = c.hidden, G = c.cp_groups;
     RowMap rm;
     rm.slot_base = 0;
@@ -15,19 +16,21 @@ int cp_frame(hipStream_t s, const Model& m, Work& w, KVCache& kv, int R, const C
     rm.pos_stride = 0;
     // position 0: the talker hidden (code_predictor_server.py:121-122)
     rm.pos_base = 0;
-    if (run_stack(s, m, m.cp, w, kv, R, rm, 256)) return -1;
+    if (run_stack(s, m, m.cp, w, kv, R, rm, 256, row0)) return -1;
     // position 1: TALKER codec embedding of code_0 (:97-98,123-124)
-    if (launch_gather_embed(s, m.talker_emb, c.talker_vocab, H, io.codes, 0, io.n_frames, io.frame_cap, 0, w.h, w.ssq, R))
+    if (launch_gather_embed(s, m.talker_emb, c.talker_vocab, H, io.codes, 0, io.n_frames, io.frame_cap, 0, w.h, w.ssq, R,
+                            row0, R_total))
         return -1;
     for (int g = 0; g < G; g++) {
         rm.pos_base = g + 1;
-        if (run_stack(s, m, m.cp, w, kv, R, rm, 256)) return -1;
+        if (run_stack(s, m, m.cp, w, kv, R, rm, 256, row0)) return -1;
         // final RMSNorm folded into the head GEMV's prologue (code_predictor_server.py:129,136)
         LinArgs a;
         a.wp = m.cp_head[g].wp;
         a.N = c.cp_vocab;
         a.K = H;
-        a.M = R;
+        a.M = row0 + R;
+        a.m_begin = row0;
         a.nt = 0;
         a.h = w.h;
         a.ssq = w.ssq;
@@ -41,6 +44,8 @@ int cp_frame(hipStream_t s, const Model& m, Work& w, KVCache& kv, int R, const C
         x.logits = w.logits;
         x.V = c.cp_vocab;
         x.R = R;
+        x.row0 = row0;
+        x.R_total = R_total;
         x.H = H;
         x.group = g;
         x.codes = io.codes;

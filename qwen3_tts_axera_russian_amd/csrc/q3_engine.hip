@@ -7,6 +7,8 @@
 #include "../../include/qwen3tts_engine.h"
 #include "q3_cp.h"
 
+#include <chrono>
+
 using namespace q3;
 
 namespace {
@@ -27,15 +29,19 @@ struct Engine {
     float* d_pad = nullptr;
     // run state
     int B = 0, ignore_eos = 0, cap_frames = 0, frames_run = 0;
-    GraphExec graph;
-    int graph_B = 0, graph_ignore = -1, graph_cap = -1;
+    GraphExec graph[8];   // one captured frame per chain, replayed on the chain's own stream (own HW queue)
+    int graph_B = 0, graph_ignore = -1, graph_cap = -1, graph_chains = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    float last_run_ms = 0.f, last_prefill_ms = 0.f;
+    float last_run_ms = 0.f, last_prefill_ms = 0.f, last_host_launch_ms = 0.f;
     int* h_done = nullptr;  // pinned [max_batch]
+    // independent row groups of one frame run as parallel branches of the graph (latency hiding)
+    int n_chains = 1;
+    hipStream_t cs[8] = {nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[8] = {nullptr};
 };
 
-int talker_tail(Engine* e, int R, const int* row_map) {
-    // final norm (+ CP seed copy) and codec head for R rows
+int talker_tail(Engine* e, hipStream_t st, int row0, int R) {
+    // final norm (+ CP seed copy) and codec head for rows row0..row0+R-1
     const Model& m = *e->m;
     const int H = m.cfg.hidden;
     FinalNormArgs f;
@@ -45,32 +51,34 @@ int talker_tail(Engine* e, int R, const int* row_map) {
     f.gamma = m.talker.final_norm;
     f.eps = m.cfg.eps;
     f.R = R;
+    f.row0 = row0;
     f.H = H;
-    f.row_map = row_map;
     f.out_f32 = e->wt.hidden_f32;
     f.out_f16 = e->wt.hidden_f16;
     f.out_copy = e->wc.h;
     f.out_copy_ssq = e->wc.ssq;
-    if (launch_final_norm(e->s, f)) return -1;
+    if (launch_final_norm(st, f)) return -1;
     LinArgs a;
     a.wp = m.talker_head.wp;
     a.N = m.cfg.talker_vocab;
     a.K = H;
-    a.M = R;
+    a.M = row0 + R;
+    a.m_begin = row0;
     a.nt = 1;
     a.x16 = e->wt.hidden_f16;
     a.y = e->wt.logits;
     a.ldy = m.cfg.talker_vocab;
-    return launch_linear(e->s, a, PRO_F16, EPI_STORE);
+    return launch_linear(st, a, PRO_F16, EPI_STORE);
 }
 
-int frame(Engine* e) {
+int frame_chain(Engine* e, hipStream_t st, int row0, int R) {
     const Model& m = *e->m;
-    const int B = e->B;
     TalkerSampleArgs sa;
     sa.logits = e->wt.logits;
     sa.V = m.cfg.talker_vocab;
-    sa.R = B;
+    sa.R = R;
+    sa.row0 = row0;
+    sa.R_total = e->B;
     sa.audio_vocab = m.cfg.cp_vocab;
     sa.eos = m.cfg.codec_eos;
     sa.past = e->d_past;
@@ -84,7 +92,7 @@ int frame(Engine* e) {
     sa.pos = e->d_posdec;
     sa.ignore_eos = e->ignore_eos;
     sa.max_frames = e->cap_frames;
-    if (launch_talker_sample(e->s, sa)) return -1;
+    if (launch_talker_sample(st, sa)) return -1;
     CpFrameIO io;
     io.codes = e->d_codes;
     io.n_frames = e->d_nframes;
@@ -92,12 +100,45 @@ int frame(Engine* e) {
     io.fb_h = e->wt.h;
     io.fb_ssq = e->wt.ssq;
     io.pad_embed = e->d_pad;
-    if (cp_frame(e->s, m, e->wc, e->kv_c, B, io)) return -1;
+    if (cp_frame(st, m, e->wc, e->kv_c, R, io, row0, e->B)) return -1;
     RowMap rm;
     rm.slot = e->d_iota;
     rm.pos = e->d_posdec;
-    if (run_stack(e->s, m, m.talker, e->wt, e->kv_t, B, rm, 1024)) return -1;
-    return talker_tail(e, B, nullptr);
+    if (run_stack(st, m, m.talker, e->wt, e->kv_t, R, rm, 1024, row0)) return -1;
+    return talker_tail(e, st, row0, R);
+}
+
+int n_chains_eff(const Engine* e) { return e->n_chains > e->B ? e->B : (e->n_chains < 1 ? 1 : e->n_chains); }
+
+void chain_rows(const Engine* e, int c, int& row0, int& R) {
+    const int nc = n_chains_eff(e);
+    row0 = 0;
+    for (int i = 0; i < c; i++) row0 += e->B / nc + (i < e->B % nc ? 1 : 0);
+    R = e->B / nc + (c < e->B % nc ? 1 : 0);
+}
+
+// one frame of every chain, eagerly, each on its own stream
+int frame_eager(Engine* e) {
+    const int nc = n_chains_eff(e);
+    for (int c = 0; c < nc; c++) {
+        int row0, R;
+        chain_rows(e, c, row0, R);
+        if (frame_chain(e, e->cs[c], row0, R)) return -1;
+    }
+    return 0;
+}
+
+int fork_chains(Engine* e) {   // chain streams start after everything queued on the main stream
+    Q3_HIP(hipEventRecord(e->ev_fork, e->s), -1);
+    for (int c = 0; c < n_chains_eff(e); c++) Q3_HIP(hipStreamWaitEvent(e->cs[c], e->ev_fork, 0), -1);
+    return 0;
+}
+int join_chains(Engine* e) {   // the main stream continues after every chain stream
+    for (int c = 0; c < n_chains_eff(e); c++) {
+        Q3_HIP(hipEventRecord(e->ev_join[c], e->cs[c]), -1);
+        Q3_HIP(hipStreamWaitEvent(e->s, e->ev_join[c], 0), -1);
+    }
+    return 0;
 }
 
 }  // namespace
@@ -108,7 +149,7 @@ void q3e_free(void* ee) {
     Engine* e = (Engine*)ee;
     if (!e) return;
     if (e->s) hipStreamSynchronize(e->s);
-    e->graph.reset();
+    for (auto& g : e->graph) g.reset();
     kv_free(e->kv_t);
     kv_free(e->kv_c);
     work_free(e->wt);
@@ -118,6 +159,11 @@ void q3e_free(void* ee) {
     for (void* p : ps)
         if (p) hipFree(p);
     if (e->h_done) hipHostFree(e->h_done);
+    for (int c = 0; c < 8; c++) {
+        if (e->cs[c]) hipStreamDestroy(e->cs[c]);
+        if (e->ev_join[c]) hipEventDestroy(e->ev_join[c]);
+    }
+    if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
     if (e->s) hipStreamDestroy(e->s);
@@ -141,8 +187,14 @@ void* q3e_create(const char* weights, int max_batch, int n_ctx, int max_frames) 
     e->max_frames = max_frames;
     const ModelCfg& c = m->cfg;
     e->prefill_rows = max_batch > 2048 ? max_batch : 2048;
-    bool ok = hipStreamCreate(&e->s) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&e->s, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreate(&e->ev0) == hipSuccess && hipEventCreate(&e->ev1) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int c = 0; c < 8 && ok; c++)
+        ok = hipStreamCreateWithFlags(&e->cs[c], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&e->ev_join[c], hipEventDisableTiming) == hipSuccess;
+    if (const char* nc = getenv("Q3_CHAINS")) e->n_chains = atoi(nc) < 1 ? 1 : atoi(nc) > 8 ? 8 : atoi(nc);
+    else e->n_chains = max_batch >= 16 ? 2 : 1;
     ok = ok && kv_alloc(e->kv_t, c.talker_layers, max_batch, c.n_kv, n_ctx) == 0;
     ok = ok && kv_alloc(e->kv_c, c.cp_layers, max_batch, c.n_kv, c.cp_groups + 1) == 0;
     ok = ok && work_alloc(e->wt, c, e->prefill_rows, c.talker_ffn, c.talker_vocab) == 0;
@@ -168,6 +220,16 @@ void* q3e_create(const char* weights, int max_batch, int n_ctx, int max_frames) 
         return nullptr;
     }
     return e;
+}
+
+int q3e_set_chains(void* ee, int n) {
+    Engine* e = (Engine*)ee;
+    if (!e || n < 1 || n > 8) return -1;
+    if (n != e->n_chains) {
+        e->n_chains = n;
+        for (auto& g : e->graph) g.reset();  // the captured frames cover the old row ranges
+    }
+    return 0;
 }
 
 int q3e_set_pad_embed(void* ee, const float* pad) {
@@ -279,52 +341,59 @@ int q3e_run(void* ee, int n_frames) {
     Engine* e = (Engine*)ee;
     if (!e || e->B <= 0 || n_frames <= 0) return -1;
     int done_frames = 0;
+    const int nc = n_chains_eff(e);
     Q3_HIP(hipEventRecord(e->ev0, e->s), -1);
-    // Q3_NO_GRAPH=1: eager launches (rocprofv3 --kernel-trace crashes on the 575-node graph replay)
+    if (fork_chains(e)) return -1;
+    // Q3_NO_GRAPH=1: eager launches (rocprofv3 --kernel-trace crashes on the graph replay)
     static const bool no_graph = getenv("Q3_NO_GRAPH") && atoi(getenv("Q3_NO_GRAPH")) != 0;
+    const bool need_capture = !e->graph[0].e || e->graph_B != e->B || e->graph_ignore != e->ignore_eos ||
+                              e->graph_cap != e->cap_frames || e->graph_chains != nc;
     if (no_graph) {
         for (; done_frames < n_frames; done_frames++)
-            if (frame(e)) return -1;
-        Q3_HIP(hipEventRecord(e->ev1, e->s), -1);
-        Q3_HIP(hipStreamSynchronize(e->s), -1);
-        hipEventElapsedTime(&e->last_run_ms, e->ev0, e->ev1);
-        e->frames_run += done_frames;
-        return done_frames;
-    }
-    const bool need_capture = !e->graph.e || e->graph_B != e->B || e->graph_ignore != e->ignore_eos ||
-                              e->graph_cap != e->cap_frames;
-    if (need_capture) {
-        // first frame eagerly (real work; also sets the kernels' LDS attributes), then capture
-        if (frame(e)) return -1;
+            if (frame_eager(e)) return -1;
+    } else if (need_capture) {
+        // first frame eagerly (real work; also sets the kernels' LDS attributes), then capture per chain
+        if (frame_eager(e)) return -1;
         done_frames++;
-        Q3_HIP(hipStreamSynchronize(e->s), -1);
-        e->graph.reset();
-        Q3_HIP(hipStreamBeginCapture(e->s, hipStreamCaptureModeRelaxed), -1);
-        int rc = frame(e);
-        hipError_t er = hipStreamEndCapture(e->s, &e->graph.g);
-        if (rc || er != hipSuccess) {
-            Q3_LOG("q3e_run: graph capture failed");
-            return -1;
+        for (int c = 0; c < nc; c++) Q3_HIP(hipStreamSynchronize(e->cs[c]), -1);
+        for (int c = 0; c < nc; c++) {
+            int row0, R;
+            chain_rows(e, c, row0, R);
+            e->graph[c].reset();
+            Q3_HIP(hipStreamBeginCapture(e->cs[c], hipStreamCaptureModeRelaxed), -1);
+            int rc = frame_chain(e, e->cs[c], row0, R);
+            hipError_t er = hipStreamEndCapture(e->cs[c], &e->graph[c].g);
+            if (rc || er != hipSuccess) {
+                Q3_LOG("q3e_run: graph capture failed");
+                return -1;
+            }
+            Q3_HIP(hipGraphInstantiate(&e->graph[c].e, e->graph[c].g, nullptr, nullptr, 0), -1);
         }
-        Q3_HIP(hipGraphInstantiate(&e->graph.e, e->graph.g, nullptr, nullptr, 0), -1);
         e->graph_B = e->B;
         e->graph_ignore = e->ignore_eos;
         e->graph_cap = e->cap_frames;
+        e->graph_chains = nc;
     }
     const int check_every = 16;
-    while (done_frames < n_frames) {
+    const auto th0 = std::chrono::steady_clock::now();
+    while (!no_graph && done_frames < n_frames) {
         int chunk = n_frames - done_frames;
         if (!e->ignore_eos && chunk > check_every) chunk = check_every;
-        for (int i = 0; i < chunk; i++) Q3_HIP(hipGraphLaunch(e->graph.e, e->s), -1);
+        for (int i = 0; i < chunk; i++)
+            for (int c = 0; c < nc; c++) Q3_HIP(hipGraphLaunch(e->graph[c].e, e->cs[c]), -1);
         done_frames += chunk;
         if (!e->ignore_eos && done_frames < n_frames) {
+            if (join_chains(e)) return -1;
             Q3_HIP(hipMemcpyAsync(e->h_done, e->d_done, sizeof(int) * e->B, hipMemcpyDeviceToHost, e->s), -1);
             Q3_HIP(hipStreamSynchronize(e->s), -1);
             bool all = true;
             for (int b = 0; b < e->B; b++) all = all && e->h_done[b];
             if (all) break;
+            if (fork_chains(e)) return -1;
         }
     }
+    e->last_host_launch_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
+    if (join_chains(e)) return -1;
     Q3_HIP(hipEventRecord(e->ev1, e->s), -1);
     Q3_HIP(hipStreamSynchronize(e->s), -1);
     hipEventElapsedTime(&e->last_run_ms, e->ev0, e->ev1);
@@ -333,6 +402,7 @@ int q3e_run(void* ee, int n_frames) {
 }
 
 float q3e_last_run_ms(void* ee) { return ee ? ((Engine*)ee)->last_run_ms : -1.f; }
+float q3e_last_host_launch_ms(void* ee) { return ee ? ((Engine*)ee)->last_host_launch_ms : -1.f; }
 float q3e_last_prefill_ms(void* ee) { return ee ? ((Engine*)ee)->last_prefill_ms : -1.f; }
 
 int q3e_get_codes(void* ee, int32_t* out, int max_out_frames, int32_t* n_frames_per_utt) {

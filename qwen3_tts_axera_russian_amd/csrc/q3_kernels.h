@@ -15,7 +15,8 @@ enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2 };
 // y[M][N] = A[M][K] . W[N][K]^T with W in MFMA-fragment order (see pack_linear).
 struct LinArgs {
     const half_t* wp = nullptr;  // packed weights
-    int N = 0, K = 0, M = 0;
+    int N = 0, K = 0, M = 0;   // rows [m_begin, M) are computed
+    int m_begin = 0;
     int nt = 0;  // 1: stream the weights with non-temporal loads (read once per step: talker)
     // prologue PRO_F16: A = x16[M][K] (fp16).  PRO_NORM: A = fp16((h*inv)*gamma),
     // inv[m] = 1/sqrt(sum(ssq[m][0..ssq_parts))/K + eps).
@@ -44,7 +45,7 @@ int launch_pack_linear(hipStream_t s, const half_t* src, int N, int K, half_t* d
 enum { ATTN_FUSED = 0, ATTN_PREP = 1, ATTN_ATTEND = 2 };
 struct AttnArgs {
     float* qkv = nullptr;  // [R][ld]: q heads, then k heads, then v heads (raw projections)
-    int ld = 0, R = 0;
+    int ld = 0, R = 0, row0 = 0;   // rows row0 .. row0+R-1
     const float* q_norm = nullptr;
     const float* k_norm = nullptr;
     float eps = 1e-6f;
@@ -73,7 +74,7 @@ struct FinalNormArgs {
     int ssq_parts = 0;
     const float* gamma = nullptr;
     float eps = 1e-6f;
-    int R = 0, H = 0;
+    int R = 0, H = 0, row0 = 0;    // output rows row0 .. row0+R-1
     const int* row_map = nullptr;  // optional: source row of output row r
     float* out_f32 = nullptr;
     half_t* out_f16 = nullptr;
@@ -86,12 +87,13 @@ int launch_final_norm(hipStream_t s, const FinalNormArgs& a);
 // when n_frames is null, else column `col` of row r's current frame in a codes array laid out as in
 // TalkerSampleArgs (frame = n_frames[r]-1, clamped to [0, frame_cap)).
 int launch_gather_embed(hipStream_t s, const float* table, int V, int H, const int* tok, int tok_stride,
-                        const int* n_frames, int frame_cap, int col, float* h, float* ssq, int R);
+                        const int* n_frames, int frame_cap, int col, float* h, float* ssq, int R, int row0 = 0,
+                        int R_total = 0);
 
 // Talker sampling (llamacpp_talker_server.py:163-206, greedy form).
 struct TalkerSampleArgs {
     const float* logits = nullptr;  // [R][V]
-    int V = 0, R = 0;
+    int V = 0, R = 0, row0 = 0, R_total = 0;   // rows row0..row0+R-1 of a batch of R_total (0 = R)
     int audio_vocab = 2048, eos = 2150;
     int* past = nullptr;    // [R][32] ring of emitted code_0
     int* n_past = nullptr;  // [R]
@@ -114,7 +116,7 @@ int launch_talker_sample(hipStream_t s, const TalkerSampleArgs& a);
 // of tts_client.py:199-208 after the last group).
 struct CpArgmaxArgs {
     const float* logits = nullptr;  // [R][V]
-    int V = 0, R = 0, H = 0;
+    int V = 0, R = 0, H = 0, row0 = 0, R_total = 0;
     int group = 0;                 // writes column group+1 of the row's current frame
     int* codes = nullptr;          // as in TalkerSampleArgs (frame = n_frames[r]-1)
     const int* n_frames = nullptr;

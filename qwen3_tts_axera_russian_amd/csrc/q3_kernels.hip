@@ -20,6 +20,32 @@ namespace q3 {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+// ---- diagnostic timeline (only in the -DQ3_TIMELINE build; the product build compiles it away) ----
+#ifdef Q3_TIMELINE
+__device__ unsigned long long* g_tl = nullptr;   // [cap][2] start/end stamps (100 MHz wall clock)
+__device__ unsigned int g_tl_idx = 0;
+__device__ unsigned int g_tl_cap = 0;
+__device__ int g_skip = 0;   // diagnostic: every kernel returns at once (measures the pure dispatch chain)
+struct TlScope {
+    unsigned int slot = 0xffffffffu;
+    int id;
+    __device__ __forceinline__ TlScope(int id_) : id(id_) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && g_tl) {
+            slot = atomicAdd(&g_tl_idx, 1u);
+            if (slot < g_tl_cap) g_tl[2 * slot] = (wall_clock64() << 8) | (unsigned)id;
+        }
+    }
+    __device__ __forceinline__ ~TlScope() {
+        if (slot < g_tl_cap) g_tl[2 * slot + 1] = wall_clock64();
+    }
+};
+#define Q3_TL(id)      \
+    if (g_skip) return; \
+    TlScope tl_scope_(id)
+#else
+#define Q3_TL(id)
+#endif
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -86,22 +112,24 @@ __global__ void __launch_bounds__(NW * 64) linear_kernel(LinArgs a) {
     constexpr int NOUT = (EPI == EPI_SWIGLU) ? MR * NB / 2 : MR * NB;   // outputs of this workgroup
     constexpr int OPT = (NOUT + NTH - 1) / NTH;                         // outputs per thread
     constexpr int SQI = (MR * 16 + NTH - 1) / NTH;                      // ssq float4 groups per thread
+    Q3_TL(10 + PRO * 4 + EPI);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int q = lane >> 4, c = lane & 15;
     const int tile0 = blockIdx.x * NB16;
-    const int m0 = blockIdx.y * MR;
+    const int m0 = a.m_begin + blockIdx.y * MR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)smem;             // [NW][MR][NBP]
     float* inv_s = red + NW * MR * NBP;    // [MR]
 
-    // ---- 1. every global load of the kernel is issued here, activation-side first ----
-    // vmcnt retires in order: the small L2-resident operands must not queue behind the HBM weight
-    // stream, and nothing later in the kernel starts a second memory round trip.
+    // ---- 1. every global load of the kernel is issued here: nothing later starts a second memory
+    // round trip.  vmcnt retires in order, so the few operands that gate the prologue go first, the
+    // HBM weight stream next, and the L2-resident fragments (needed only together with the weights) last.
     float4 sq[SQI];
     float4 hraw[MT16][KBW][2];
     float4 graw[KBW][2];
     h8 af[MT16][KBW];
     float hold[OPT];
+    // (a) tiny operands that gate the prologue / epilogue
     if (PRO == PRO_NORM) {
 #pragma unroll
         for (int i = 0; i < SQI; i++) {
@@ -110,6 +138,27 @@ __global__ void __launch_bounds__(NW * 64) linear_kernel(LinArgs a) {
             sq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (g4 < MR * 16 && m < a.M) sq[i] = *(const float4*)(a.ssq + (size_t)m * 64 + (g4 & 15) * 4);
         }
+    }
+    if (EPI == EPI_RESID) {
+#pragma unroll
+        for (int i = 0; i < OPT; i++) {
+            const int o = tid + i * NTH;
+            const int m = m0 + o / NB;
+            hold[i] = 0.f;
+            if (o < NOUT && m < a.M) hold[i] = a.h_out[(size_t)m * a.N + tile0 * 16 + (o % NB)];
+        }
+    }
+    // (b) the weight stream (HBM, the long pole): everything this wave will need, in flight at once
+    h8 wf[NB16][KBW];
+#pragma unroll
+    for (int nb = 0; nb < NB16; nb++)
+#pragma unroll
+        for (int kbi = 0; kbi < KBW; kbi++) {
+            const h8* p = (const h8*)(a.wp + (((size_t)(tile0 + nb) * KB + (size_t)w * KBW + kbi) * 64 + lane) * 8);
+            wf[nb][kbi] = NT ? __builtin_nontemporal_load(p) : *p;
+        }
+    // (c) the activation fragments (L2)
+    if (PRO == PRO_NORM) {
 #pragma unroll
         for (int kbi = 0; kbi < KBW; kbi++) {
             const int k0 = (w * KBW + kbi) * 32 + q * 8;
@@ -135,24 +184,6 @@ __global__ void __launch_bounds__(NW * 64) linear_kernel(LinArgs a) {
             }
         }
     }
-    if (EPI == EPI_RESID) {
-#pragma unroll
-        for (int i = 0; i < OPT; i++) {
-            const int o = tid + i * NTH;
-            const int m = m0 + o / NB;
-            hold[i] = 0.f;
-            if (o < NOUT && m < a.M) hold[i] = a.h_out[(size_t)m * a.N + tile0 * 16 + (o % NB)];
-        }
-    }
-    // the weight stream: everything this wave will need, in flight at once
-    h8 wf[NB16][KBW];
-#pragma unroll
-    for (int nb = 0; nb < NB16; nb++)
-#pragma unroll
-        for (int kbi = 0; kbi < KBW; kbi++) {
-            const h8* p = (const h8*)(a.wp + (((size_t)(tile0 + nb) * KB + (size_t)w * KBW + kbi) * 64 + lane) * 8);
-            wf[nb][kbi] = NT ? __builtin_nontemporal_load(p) : *p;
-        }
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- 2. RMSNorm scale per row from the producer's 64 sum-of-squares partials (a.ssq_parts == 64) ----
@@ -274,7 +305,7 @@ static int launch_linear_nt(hipStream_t s, const LinArgs& a) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), -1);
         attr_set = true;
     }
-    dim3 grid(a.N / (16 * NB16), (a.M + MR - 1) / MR);
+    dim3 grid(a.N / (16 * NB16), (a.M - a.m_begin + MR - 1) / MR);
     hipLaunchKernelGGL((linear_kernel<NB16, MT16, KBW, NW, PRO, EPI, NT>), grid, dim3(NW * 64), lds, s, a);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
@@ -287,6 +318,8 @@ static int launch_linear_t(hipStream_t s, const LinArgs& a) {
 }
 
 // (KBW, NW) per K; overridable for tuning through q3_set_linear_tuning().
+static int g_split_rows_narrow = 1;
+int set_linear_split_rows(int on) { g_split_rows_narrow = on; return 0; }
 // k-blocks per wave by [K = 1024, 2048, 3072][rows <= 16, <= 32, more]
 static int g_tune_kbw[3][3] = {{8, 4, 4}, {8, 8, 8}, {6, 6, 6}};
 int set_linear_tuning(int K, int mt16, int kbw) {
@@ -307,14 +340,18 @@ int set_linear_tuning(int K, int mt16, int kbw) {
     Q3_LIN_CASE(NB16_, 4, KBW_, NW_, PRO_, EPI_)
 
 int launch_linear(hipStream_t s, const LinArgs& a, int pro, int epi) {
-    if (a.M <= 0) return 0;
+    const int rows = a.M - a.m_begin;
+    if (rows <= 0) return 0;
     const int K = a.K;
     int ki = K == 1024 ? 0 : K == 2048 ? 1 : K == 3072 ? 2 : -1;
     if (ki < 0 || a.N % 32) {
         Q3_LOG("launch_linear: unsupported shape N=%d K=%d", a.N, K);
         return -1;
     }
-    const int mt16 = a.M <= 16 ? 1 : a.M <= 32 ? 2 : 4;
+    int mt16 = rows <= 16 ? 1 : rows <= 32 ? 2 : 4;
+    // narrow outputs (o/down, N = 1024) have only N/16 = 64 column tiles: split the rows over two
+    // workgroups per tile instead (same XCD under round-robin placement, the weights come once from HBM)
+    if (rows > 16 && rows <= 32 && ((g_split_rows_narrow == 1 && a.N <= 1024) || g_split_rows_narrow == 2)) mt16 = 1;
     const int kbw = g_tune_kbw[ki][mt16 == 1 ? 0 : mt16 == 2 ? 1 : 2];
     const int nw = K / 32 / kbw;
     const int nb16 = (epi == EPI_SWIGLU) ? 2 : 1;
@@ -359,8 +396,9 @@ int launch_ssq_rows(hipStream_t s, const float* h, float* ssq, int R, int H) {
 // final RMSNorm of selected rows
 // ---------------------------------------------------------------------------
 __global__ void final_norm_kernel(FinalNormArgs a) {
+    Q3_TL(40);
     __shared__ float inv_sh;
-    const int r = blockIdx.x;
+    const int r = a.row0 + blockIdx.x;
     const int src = a.row_map ? a.row_map[r] : r;
     if (threadIdx.x < 64) {
         float s = 0.f;
@@ -415,14 +453,15 @@ __device__ __forceinline__ void store_row_ssq(float* h, float* ssq, int r, int H
 
 __global__ void gather_embed_kernel(const float* __restrict__ table, int V, int H, const int* __restrict__ tok,
                                     int tok_stride, const int* __restrict__ n_frames, int frame_cap, int col,
-                                    float* __restrict__ h, float* __restrict__ ssq) {
-    const int r = blockIdx.x;
+                                    float* __restrict__ h, float* __restrict__ ssq, int row0, int R_total) {
+    Q3_TL(41);
+    const int r = row0 + blockIdx.x;
     int t;
     if (n_frames) {
         int f = n_frames[r] - 1;
         if (f < 0) f = 0;
         if (f >= frame_cap) f = frame_cap - 1;
-        t = tok[((size_t)f * gridDim.x + r) * 16 + col];
+        t = tok[((size_t)f * R_total + r) * 16 + col];
     } else {
         t = tok[(size_t)r * tok_stride];
     }
@@ -434,31 +473,37 @@ __global__ void gather_embed_kernel(const float* __restrict__ table, int V, int 
     }
 }
 int launch_gather_embed(hipStream_t s, const float* table, int V, int H, const int* tok, int tok_stride,
-                        const int* n_frames, int frame_cap, int col, float* h, float* ssq, int R) {
+                        const int* n_frames, int frame_cap, int col, float* h, float* ssq, int R, int row0,
+                        int R_total) {
     if (R <= 0) return 0;
     hipLaunchKernelGGL(gather_embed_kernel, dim3(R), dim3(256), 0, s, table, V, H, tok, tok_stride, n_frames,
-                       frame_cap, col, h, ssq);
+                       frame_cap, col, h, ssq, row0, R_total > 0 ? R_total : R);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
 }
 
 // ---------------------------------------------------------------------------
-// attention
+// attention: one workgroup per (row, kv head).  Phase A (waves 0-3): per-head RMSNorm + RoPE of the
+// two q heads and the k head, v pass-through, K/V appended to the cache.  Phase B: every 16-lane
+// group walks cached rows t = grp, grp+ngrp, ... (16 B of K and of V per lane, straight to VGPRs)
+// with an online softmax per group, groups are merged by shuffles inside a wave and through LDS
+// across waves: two barriers in all, no n_ctx-sized LDS.
 // ---------------------------------------------------------------------------
 template <int MODE>
 __global__ void __launch_bounds__(1024) attn_kernel(AttnArgs a) {
     constexpr int D = 128;
-    const int r = blockIdx.x, g = blockIdx.y;
+    Q3_TL(30 + MODE);
+    const int r = a.row0 + blockIdx.x, g = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nwv = blockDim.x >> 6;
     const int slot = a.slot ? a.slot[r] : a.slot_base + r * a.slot_stride;
     const int pos = a.pos ? a.pos[r] : a.pos_base + r * a.pos_stride;
     __shared__ float qs[2][D];
     __shared__ float knew[D], vnew[D];
-    __shared__ float redbuf[64];
     extern __shared__ __attribute__((aligned(16))) float dyn[];
-    float* sc = dyn;                       // [2][n_ctx]
-    float* pv = dyn + 2 * (size_t)a.n_ctx; // [nwv][2][D]
+    float* pm = dyn;                    // [nwv][2]  running max per wave/head
+    float* pl = dyn + 2 * nwv;          // [nwv][2]  running sum
+    float* pacc = dyn + 4 * nwv;        // [nwv][2][D]
     float* row = a.qkv + (size_t)r * a.ld;
     const size_t cbase = ((size_t)slot * a.n_kv + g) * (size_t)a.n_ctx * D;
     const int T = (MODE == ATTN_FUSED) ? pos : pos + 1;  // rows read from the cache
@@ -466,8 +511,8 @@ __global__ void __launch_bounds__(1024) attn_kernel(AttnArgs a) {
     const half_t* kbase = a.kc + cbase;
     const half_t* vbase = a.vc + cbase;
 
-    // ---- phase A loads first (they are consumed first; vmcnt retires in order), then the first
-    // APRE cached K and V rows of every 16-lane group: one memory round trip covers T <= APRE*ngrp ----
+    // ---- all loads of the short-T case are issued here: phase A operands first (consumed first;
+    // vmcnt retires in order), then the first APRE cached K/V rows of every group ----
     float x0 = 0.f, x1 = 0.f, gm0 = 1.f, gm1 = 1.f, cs = 1.f, sn = 0.f;
     if (MODE != ATTN_ATTEND && w < 4) {
         // wave 0,1: q heads 2g, 2g+1; wave 2: k head g; wave 3: v head g
@@ -538,39 +583,19 @@ __global__ void __launch_bounds__(1024) attn_kernel(AttnArgs a) {
     }
     __syncthreads();
 
-    // ---- phase B: scores.  16 lanes per cached row (16 B each), 4 rows per wave step ----
-    const int ntot = pos + 1;
+    // ---- phase B: online softmax per 16-lane group ----
     float q0[8], q1[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        q0[j] = qs[0][l16 * 8 + j];
-        q1[j] = qs[1][l16 * 8 + j];
+        q0[j] = qs[0][l16 * 8 + j] * a.scale;   // fold the 1/sqrt(D) into q once
+        q1[j] = qs[1][l16 * 8 + j] * a.scale;
     }
+    float m0 = -INFINITY, m1 = -INFINITY, l0 = 0.f, l1 = 0.f;
+    float a0[8], a1[8];
 #pragma unroll
-    for (int i = 0; i < APRE; i++) {
-        const int t = grp + i * ngrp;
-        if (t < T) {
-            float d0 = 0.f, d1 = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const float kf = (float)kpre[i][j];
-                d0 += q0[j] * kf;
-                d1 += q1[j] * kf;
-            }
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) {
-                d0 += __shfl_xor(d0, o, 16);
-                d1 += __shfl_xor(d1, o, 16);
-            }
-            if (l16 == 0) {
-                sc[t] = d0 * a.scale;
-                sc[a.n_ctx + t] = d1 * a.scale;
-            }
-        }
-    }
-#pragma unroll 4
-    for (int t = grp + APRE * ngrp; t < T; t += ngrp) {
-        const h8 kk = *(const h8*)(kbase + (size_t)t * D + l16 * 8);
+    for (int j = 0; j < 8; j++) a0[j] = a1[j] = 0.f;
+
+    auto step = [&](const h8& kk, const h8& vv) {
         float d0 = 0.f, d1 = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -583,132 +608,86 @@ __global__ void __launch_bounds__(1024) attn_kernel(AttnArgs a) {
             d0 += __shfl_xor(d0, o, 16);
             d1 += __shfl_xor(d1, o, 16);
         }
-        if (l16 == 0) {
-            sc[t] = d0 * a.scale;
-            sc[a.n_ctx + t] = d1 * a.scale;
-        }
-    }
-    if (MODE == ATTN_FUSED && grp == 0) {
-        float d0 = 0.f, d1 = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const float kf = knew[l16 * 8 + j];
-            d0 += q0[j] * kf;
-            d1 += q1[j] * kf;
-        }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-            d0 += __shfl_xor(d0, o, 16);
-            d1 += __shfl_xor(d1, o, 16);
-        }
-        if (l16 == 0) {
-            sc[pos] = d0 * a.scale;
-            sc[a.n_ctx + pos] = d1 * a.scale;
-        }
-    }
-    __syncthreads();
-
-    // ---- softmax statistics (both heads) ----
-    float mx0 = -INFINITY, mx1 = -INFINITY;
-    for (int t = tid; t < ntot; t += blockDim.x) {
-        mx0 = fmaxf(mx0, sc[t]);
-        mx1 = fmaxf(mx1, sc[a.n_ctx + t]);
-    }
-    mx0 = wave_max(mx0);
-    mx1 = wave_max(mx1);
-    if (lane == 0) {
-        redbuf[w] = mx0;
-        redbuf[16 + w] = mx1;
-    }
-    __syncthreads();
-    mx0 = redbuf[0];
-    mx1 = redbuf[16];
-    for (int i = 1; i < nwv; i++) {
-        mx0 = fmaxf(mx0, redbuf[i]);
-        mx1 = fmaxf(mx1, redbuf[16 + i]);
-    }
-    float s0 = 0.f, s1 = 0.f;
-    for (int t = tid; t < ntot; t += blockDim.x) {
-        const float e0 = expf(sc[t] - mx0), e1 = expf(sc[a.n_ctx + t] - mx1);
-        sc[t] = e0;
-        sc[a.n_ctx + t] = e1;
-        s0 += e0;
-        s1 += e1;
-    }
-    s0 = wave_sum(s0);
-    s1 = wave_sum(s1);
-    __syncthreads();  // everyone has read the maxima
-    if (lane == 0) {
-        redbuf[32 + w] = s0;
-        redbuf[48 + w] = s1;
-    }
-    __syncthreads();
-    s0 = 0.f;
-    s1 = 0.f;
-    for (int i = 0; i < nwv; i++) {
-        s0 += redbuf[32 + i];
-        s1 += redbuf[48 + i];
-    }
-
-    // ---- P.V: 16 lanes per cached row, 8 output dims per lane ----
-    float a0[8], a1[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) a0[j] = a1[j] = 0.f;
-#pragma unroll
-    for (int i = 0; i < APRE; i++) {
-        const int t = grp + i * ngrp;
-        if (t < T) {
-            const float p0 = sc[t], p1 = sc[a.n_ctx + t];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const float vf = (float)vpre[i][j];
-                a0[j] += p0 * vf;
-                a1[j] += p1 * vf;
-            }
-        }
-    }
-#pragma unroll 4
-    for (int t = grp + APRE * ngrp; t < T; t += ngrp) {
-        const h8 vv = *(const h8*)(vbase + (size_t)t * D + l16 * 8);
-        const float p0 = sc[t], p1 = sc[a.n_ctx + t];
+        const float n0 = fmaxf(m0, d0), n1 = fmaxf(m1, d1);
+        const float c0 = expf(m0 - n0), c1 = expf(m1 - n1);   // exp(-inf) = 0 on the first row
+        const float p0 = expf(d0 - n0), p1 = expf(d1 - n1);
+        l0 = l0 * c0 + p0;
+        l1 = l1 * c1 + p1;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const float vf = (float)vv[j];
-            a0[j] += p0 * vf;
-            a1[j] += p1 * vf;
+            a0[j] = a0[j] * c0 + p0 * vf;
+            a1[j] = a1[j] * c1 + p1 * vf;
         }
+        m0 = n0;
+        m1 = n1;
+    };
+#pragma unroll
+    for (int i = 0; i < APRE; i++) {
+        const int t = grp + i * ngrp;
+        if (t < T) step(kpre[i], vpre[i]);   // uniform per 16-lane group
     }
-    if (MODE == ATTN_FUSED && grp == 0) {
-        const float p0 = sc[pos], p1 = sc[a.n_ctx + pos];
+#pragma unroll 2
+    for (int t = grp + APRE * ngrp; t < T; t += ngrp) {
+        const h8 kk = *(const h8*)(kbase + (size_t)t * D + l16 * 8);
+        const h8 vv = *(const h8*)(vbase + (size_t)t * D + l16 * 8);
+        step(kk, vv);
+    }
+    if (MODE == ATTN_FUSED && grp == 0) {   // the token being appended, from LDS (fp16-rounded values)
+        h8 kk, vv;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const float vf = vnew[l16 * 8 + j];
-            a0[j] += p0 * vf;
-            a1[j] += p1 * vf;
+            kk[j] = (half_t)knew[l16 * 8 + j];
+            vv[j] = (half_t)vnew[l16 * 8 + j];
         }
+        step(kk, vv);
     }
-    // the 4 row groups of a wave hold the same dims: fold them
+    // merge the 4 groups of a wave (lanes xor 16, 32), then the waves through LDS
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        a0[j] += __shfl_xor(a0[j], 16, 64);
-        a0[j] += __shfl_xor(a0[j], 32, 64);
-        a1[j] += __shfl_xor(a1[j], 16, 64);
-        a1[j] += __shfl_xor(a1[j], 32, 64);
+    for (int o = 16; o <= 32; o <<= 1) {
+        const float om0 = __shfl_xor(m0, o, 64), om1 = __shfl_xor(m1, o, 64);
+        const float ol0 = __shfl_xor(l0, o, 64), ol1 = __shfl_xor(l1, o, 64);
+        const float n0 = fmaxf(m0, om0), n1 = fmaxf(m1, om1);
+        // a group that saw no row has m = -inf and l = 0: its scale is exp(-inf - n) = 0 unless n is -inf too
+        const float c0 = (m0 == -INFINITY) ? 0.f : expf(m0 - n0), d0 = (om0 == -INFINITY) ? 0.f : expf(om0 - n0);
+        const float c1 = (m1 == -INFINITY) ? 0.f : expf(m1 - n1), d1 = (om1 == -INFINITY) ? 0.f : expf(om1 - n1);
+        l0 = l0 * c0 + ol0 * d0;
+        l1 = l1 * c1 + ol1 * d1;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float oa0 = __shfl_xor(a0[j], o, 64), oa1 = __shfl_xor(a1[j], o, 64);
+            a0[j] = a0[j] * c0 + oa0 * d0;
+            a1[j] = a1[j] * c1 + oa1 * d1;
+        }
+        m0 = n0;
+        m1 = n1;
     }
     if (lane < 16) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            pv[(w * 2 + 0) * D + lane * 8 + j] = a0[j];
-            pv[(w * 2 + 1) * D + lane * 8 + j] = a1[j];
+            pacc[(w * 2 + 0) * D + lane * 8 + j] = a0[j];
+            pacc[(w * 2 + 1) * D + lane * 8 + j] = a1[j];
+        }
+        if (lane == 0) {
+            pm[w * 2 + 0] = m0;
+            pm[w * 2 + 1] = m1;
+            pl[w * 2 + 0] = l0;
+            pl[w * 2 + 1] = l1;
         }
     }
     __syncthreads();
     if (tid < 2 * D) {
         const int hh = tid / D, d = tid % D;
-        float o = 0.f;
-        for (int i = 0; i < nwv; i++) o += pv[(i * 2 + hh) * D + d];
-        o = o / (hh ? s1 : s0);
-        a.out[(size_t)r * (a.n_heads * D) + (size_t)(2 * g + hh) * D + d] = sat_half(o);
+        float M = -INFINITY;
+        for (int i = 0; i < nwv; i++) M = fmaxf(M, pm[i * 2 + hh]);
+        float L = 0.f, o = 0.f;
+        for (int i = 0; i < nwv; i++) {
+            const float mi = pm[i * 2 + hh];
+            const float c = (mi == -INFINITY) ? 0.f : expf(mi - M);
+            L += pl[i * 2 + hh] * c;
+            o += pacc[(i * 2 + hh) * D + d] * c;
+        }
+        a.out[(size_t)r * (a.n_heads * D) + (size_t)(2 * g + hh) * D + d] = sat_half(o / L);
     }
 }
 
@@ -724,20 +703,10 @@ int launch_attn(hipStream_t s, const AttnArgs& a, int mode) {
     if (threads > fit) threads = fit / 64 * 64;
     if (threads < 256) threads = 256;
     if (threads > 1024) threads = 1024;
-    const size_t lds = ((size_t)2 * a.n_ctx + (size_t)(threads / 64) * 2 * 128) * sizeof(float);
-    if (lds > 150 * 1024) {
-        Q3_LOG("attn: n_ctx=%d needs %zu B of LDS", a.n_ctx, lds);
-        return -1;
-    }
+    const size_t lds = ((size_t)(threads / 64) * (4 + 2 * 128)) * sizeof(float);
     dim3 grid(a.R, a.n_kv);
 #define Q3_ATTN(MODE_)                                                                                   \
     {                                                                                                    \
-        static bool set_ = false;                                                                        \
-        if (!set_) {                                                                                     \
-            Q3_HIP(hipFuncSetAttribute((const void*)attn_kernel<MODE_>,                                  \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), -1);     \
-            set_ = true;                                                                                 \
-        }                                                                                                \
         hipLaunchKernelGGL((attn_kernel<MODE_>), grid, dim3(mode == ATTN_PREP ? 256 : threads),          \
                            mode == ATTN_PREP ? 0 : lds, s, a);                                           \
     }
@@ -780,11 +749,13 @@ __device__ __forceinline__ void block_argmax(float& v, int& idx, float* sv, int*
 }
 
 __global__ void talker_sample_kernel(TalkerSampleArgs a) {
+    Q3_TL(42);
     __shared__ float sv[16];
     __shared__ int si[16];
     __shared__ int win[32];
     __shared__ int nwin;
-    const int r = blockIdx.x;
+    const int r = a.row0 + blockIdx.x;
+    const int RT = a.R_total > 0 ? a.R_total : a.R;
     const int np = a.n_past[r];
     const int nt = a.n_text[r];
     const bool was_done = a.done[r] != 0;
@@ -834,7 +805,7 @@ __global__ void talker_sample_kernel(TalkerSampleArgs a) {
         int f = a.n_frames[r];
         a.n_frames[r] = f + 1;
         if (f >= a.frame_cap) f = a.frame_cap - 1;
-        int* fc = a.codes + ((size_t)f * a.R + r) * 16;
+        int* fc = a.codes + ((size_t)f * RT + r) * 16;
         if (fin) {
             a.done[r] = 1;
             fc[0] = -1;
@@ -888,44 +859,51 @@ __device__ __forceinline__ void feedback_row(const int* codes, int r, const floa
     }
 }
 
-__global__ void cp_argmax_kernel(CpArgmaxArgs a) {
-    __shared__ float sv[16];
-    __shared__ int si[16];
-    __shared__ int tok_sh;
-    const int r = blockIdx.x;
+// One wave per row: no barriers; the logits come in as float4s, the winner leaves by shuffles.
+__global__ void __launch_bounds__(64) cp_argmax_kernel(CpArgmaxArgs a) {
+    Q3_TL(43);
+    const int r = a.row0 + blockIdx.x, lane = threadIdx.x;
+    const int RT = a.R_total > 0 ? a.R_total : a.R;
     float best = -INFINITY;
     int bidx = 0x7fffffff;
-    for (int v = threadIdx.x; v < a.V; v += blockDim.x) {
-        const float l = a.logits[(size_t)r * a.V + v];
-        if (l > best || (l == best && v < bidx)) {
-            best = l;
-            bidx = v;
+    const float4* lg = (const float4*)(a.logits + (size_t)r * a.V);
+    for (int v4 = lane; v4 < a.V / 4; v4 += 64) {
+        const float4 l = lg[v4];
+        const float e[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (e[j] > best) {   // ascending index within a lane: strict > keeps the lowest index
+                best = e[j];
+                bidx = v4 * 4 + j;
+            }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bidx, o, 64);
+        if (ov > best || (ov == best && oi < bidx)) {
+            best = ov;
+            bidx = oi;
         }
     }
-    block_argmax(best, bidx, sv, si);
     int f = a.n_frames[r] - 1;
     if (f < 0) f = 0;
     if (f >= a.frame_cap) f = a.frame_cap - 1;
-    int* fc = a.codes + ((size_t)f * a.R + r) * 16;
-    if (threadIdx.x == 0) {
-        fc[1 + a.group] = bidx;
-        tok_sh = bidx;
-    }
-    __syncthreads();
+    int* fc = a.codes + ((size_t)f * RT + r) * 16;
+    if (lane == 0) fc[1 + a.group] = bidx;
     if (a.talker_emb) {
         feedback_row(fc, r, a.talker_emb, a.talker_vocab, a.cp_tables, a.V, a.n_groups, a.pad_embed,
-                     a.h_out, a.ssq_out, a.H, a.group, tok_sh);
+                     a.h_out, a.ssq_out, a.H, a.group, bidx);
     } else if (a.next_table) {
-        const int t = tok_sh;
-        for (int k4 = threadIdx.x; k4 < a.H / 4; k4 += blockDim.x) {
-            const float4 v = *(const float4*)(a.next_table + (size_t)t * a.H + k4 * 4);
+        for (int k4 = lane; k4 < a.H / 4; k4 += 64) {
+            const float4 v = *(const float4*)(a.next_table + (size_t)bidx * a.H + k4 * 4);
             store_row_ssq(a.h_out, a.ssq_out, r, a.H, k4, v);
         }
     }
 }
 int launch_cp_argmax(hipStream_t s, const CpArgmaxArgs& a) {
     if (a.R <= 0) return 0;
-    hipLaunchKernelGGL(cp_argmax_kernel, dim3(a.R), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(cp_argmax_kernel, dim3(a.R), dim3(64), 0, s, a);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
 }
@@ -947,3 +925,36 @@ int launch_feedback(hipStream_t s, const int* codes16, int R, const float* talke
 }
 
 }  // namespace q3
+
+#ifdef Q3_TIMELINE
+namespace q3 {
+// host control of the diagnostic timeline
+int tl_begin(unsigned cap) {
+    unsigned long long* buf = nullptr;
+    if (hipMalloc((void**)&buf, (size_t)cap * 16) != hipSuccess) return -1;
+    hipMemset(buf, 0, (size_t)cap * 16);
+    unsigned zero = 0;
+    hipMemcpyToSymbol(HIP_SYMBOL(g_tl_idx), &zero, 4);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_tl_cap), &cap, 4);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_tl), &buf, sizeof(buf));
+    return 0;
+}
+int tl_end(unsigned long long* out, unsigned cap) {
+    hipDeviceSynchronize();
+    unsigned long long* buf = nullptr;
+    unsigned n = 0;
+    hipMemcpyFromSymbol(&buf, HIP_SYMBOL(g_tl), sizeof(buf));
+    hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_tl_idx), 4);
+    if (!buf) return -1;
+    if (n > cap) n = cap;
+    hipMemcpy(out, buf, (size_t)n * 16, hipMemcpyDeviceToHost);
+    unsigned long long* nul = nullptr;
+    hipMemcpyToSymbol(HIP_SYMBOL(g_tl), &nul, sizeof(nul));
+    hipFree(buf);
+    return (int)n;
+}
+}  // namespace q3
+extern "C" int q3t_set_skip(int on) { return hipMemcpyToSymbol(HIP_SYMBOL(q3::g_skip), &on, 4) == hipSuccess ? 0 : -1; }
+extern "C" int q3t_tl_begin(unsigned cap) { return q3::tl_begin(cap); }
+extern "C" int q3t_tl_end(unsigned long long* out, unsigned cap) { return q3::tl_end(out, cap); }
+#endif

@@ -71,7 +71,7 @@ struct RowMap {            // which (slot, position) each row feeds
 
 // Run every layer of `st` over R rows whose residual stream (+ssq partials) sits in w.h / w.ssq.
 int run_stack(hipStream_t s, const Model& m, const DevStack& st, Work& w, KVCache& kv, int R,
-              const RowMap& rm, int attn_threads);
+              const RowMap& rm, int attn_threads, int row0 = 0);
 
 struct GraphExec {
     hipGraph_t g = nullptr;

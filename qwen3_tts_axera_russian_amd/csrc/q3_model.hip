@@ -270,11 +270,11 @@ void work_free(Work& w) {
 }
 
 int run_stack(hipStream_t s, const Model& m, const DevStack& st, Work& w, KVCache& kv, int R, const RowMap& rm,
-              int attn_threads) {
+              int attn_threads, int row0) {
     const ModelCfg& c = m.cfg;
     const int H = c.hidden, D = c.head_dim;
     const int qkv_ld = (c.n_heads + 2 * c.n_kv) * D;
-    if (R > w.max_rows) {
+    if (row0 + R > w.max_rows) {
         Q3_LOG("run_stack: %d rows > workspace %d", R, w.max_rows);
         return -1;
     }
@@ -286,7 +286,8 @@ int run_stack(hipStream_t s, const Model& m, const DevStack& st, Work& w, KVCach
         a.wp = L.qkv.wp;
         a.N = L.qkv.N;
         a.K = H;
-        a.M = R;
+        a.M = row0 + R;
+        a.m_begin = row0;
         a.nt = st.nt;
         a.h = w.h;
         a.ssq = w.ssq;
@@ -301,6 +302,7 @@ int run_stack(hipStream_t s, const Model& m, const DevStack& st, Work& w, KVCach
         t.qkv = w.qkv;
         t.ld = qkv_ld;
         t.R = R;
+        t.row0 = row0;
         t.q_norm = L.q_norm;
         t.k_norm = L.k_norm;
         t.eps = c.eps;
@@ -331,7 +333,8 @@ int run_stack(hipStream_t s, const Model& m, const DevStack& st, Work& w, KVCach
         a.wp = L.o.wp;
         a.N = H;
         a.K = L.o.K;
-        a.M = R;
+        a.M = row0 + R;
+        a.m_begin = row0;
         a.nt = st.nt;
         a.x16 = w.attn;
         a.h_out = w.h;
@@ -342,7 +345,8 @@ int run_stack(hipStream_t s, const Model& m, const DevStack& st, Work& w, KVCach
         a.wp = L.gu.wp;
         a.N = L.gu.N;
         a.K = H;
-        a.M = R;
+        a.M = row0 + R;
+        a.m_begin = row0;
         a.nt = st.nt;
         a.h = w.h;
         a.ssq = w.ssq;
@@ -356,7 +360,8 @@ int run_stack(hipStream_t s, const Model& m, const DevStack& st, Work& w, KVCach
         a.wp = L.down.wp;
         a.N = H;
         a.K = L.down.K;
-        a.M = R;
+        a.M = row0 + R;
+        a.m_begin = row0;
         a.nt = st.nt;
         a.x16 = w.act;
         a.h_out = w.h;

@@ -1,10 +1,12 @@
 // q3_test_api.hip -- kernel-level entry points used only by tests/ (host arrays in, host arrays out).
 #include "q3_model.h"
+#include <chrono>
 
 using namespace q3;
 
 namespace q3 {
 int set_linear_tuning(int K, int mt16, int kbw);
+int set_linear_split_rows(int on);
 }
 
 namespace {
@@ -27,6 +29,7 @@ int q3t_device_count(void) {
 }
 
 int q3t_set_linear_tuning(int K, int mt16, int kbw) { return set_linear_tuning(K, mt16, kbw); }
+int q3t_set_linear_split_rows(int on) { return set_linear_split_rows(on); }
 
 // One linear launch.  W is row-major fp16 [N][K]; gateup != 0 means rows [0,N/2) are gate and
 // [N/2,N) up (tile-interleaved on the device like the model loader does).
@@ -237,4 +240,53 @@ extern "C" float q3t_bench_chain(int kind, int blocks, int threads, int n_kernel
     hipEventDestroy(e1);
     hipStreamDestroy(s);
     return ms * 1000.f / ((float)iters * n_kernels);
+}
+
+// Do graphs replayed on different streams overlap on this runtime?  n_streams graphs, each an
+// n_kernels-long dependent chain; returns the wall microseconds for one round of all graphs.
+extern "C" float q3t_bench_multistream(int n_streams, int blocks, int threads, int n_kernels, int iters, int use_graph) {
+    if (n_streams < 1 || n_streams > 8) return -1.f;
+    hipStream_t st[8];
+    hipGraph_t g[8] = {nullptr};
+    hipGraphExec_t ge[8] = {nullptr};
+    DBuf a[8], b[8];
+    const int n = blocks * threads;
+    for (int s = 0; s < n_streams; s++) {
+        if (hipStreamCreateWithFlags(&st[s], hipStreamNonBlocking) != hipSuccess) return -1.f;
+        if (!a[s].alloc((size_t)n * 4) || !b[s].alloc((size_t)n * 4)) return -1.f;
+        hipMemset(a[s].p, 0, (size_t)n * 4);
+        hipMemset(b[s].p, 0, (size_t)n * 4);
+    }
+    auto chain = [&](int s) {
+        for (int k = 0; k < n_kernels; k++) {
+            float* in = (float*)((k & 1) ? b[s].p : a[s].p);
+            float* out = (float*)((k & 1) ? a[s].p : b[s].p);
+            hipLaunchKernelGGL(chain_dep_kernel, dim3(blocks), dim3(threads), 0, st[s], in, out, n, 2);
+        }
+    };
+    for (int s = 0; s < n_streams; s++) {
+        chain(s);
+        hipStreamSynchronize(st[s]);
+        if (use_graph) {
+            hipStreamBeginCapture(st[s], hipStreamCaptureModeRelaxed);
+            chain(s);
+            if (hipStreamEndCapture(st[s], &g[s]) != hipSuccess) return -1.f;
+            if (hipGraphInstantiate(&ge[s], g[s], nullptr, nullptr, 0) != hipSuccess) return -1.f;
+        }
+    }
+    hipDeviceSynchronize();
+    auto t0 = std::chrono::steady_clock::now();
+    for (int it = 0; it < iters; it++)
+        for (int s = 0; s < n_streams; s++) {
+            if (use_graph) hipGraphLaunch(ge[s], st[s]);
+            else chain(s);
+        }
+    hipDeviceSynchronize();
+    auto t1 = std::chrono::steady_clock::now();
+    for (int s = 0; s < n_streams; s++) {
+        if (ge[s]) hipGraphExecDestroy(ge[s]);
+        if (g[s]) hipGraphDestroy(g[s]);
+        hipStreamDestroy(st[s]);
+    }
+    return (float)(std::chrono::duration<double, std::micro>(t1 - t0).count() / iters);
 }

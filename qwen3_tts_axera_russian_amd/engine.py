@@ -18,6 +18,10 @@ class FrameEngine:
         self.max_batch, self.n_ctx, self.max_frames = max_batch, n_ctx, max_frames
         self.B = 0
 
+    def set_chains(self, n):
+        if self._lib.q3e_set_chains(self.h, int(n)) != 0:
+            raise RuntimeError("q3e_set_chains failed")
+
     def set_pad_embed(self, pad):
         pad = np.ascontiguousarray(pad, dtype=np.float32).reshape(-1)
         if self._lib.q3e_set_pad_embed(self.h, hiplib.fptr(pad)) != 0:

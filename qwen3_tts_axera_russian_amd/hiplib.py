@@ -61,6 +61,7 @@ def load(path: str | None = None):
     _sig(lib, "q3e_create", c_void_p, [c_char_p, c_int, c_int, c_int])
     _sig(lib, "q3e_free", None, [c_void_p])
     _sig(lib, "q3e_set_pad_embed", c_int, [c_void_p, f32p])
+    _sig(lib, "q3e_set_chains", c_int, [c_void_p, c_int])
     _sig(lib, "q3e_start", c_int, [c_void_p, c_int, f32p, i32p, i32p, c_int, c_int])
     _sig(lib, "q3e_run", c_int, [c_void_p, c_int])
     _sig(lib, "q3e_last_run_ms", c_float, [c_void_p])
@@ -75,6 +76,7 @@ def load(path: str | None = None):
     _sig(lib, "q3t_linear", c_int, [c_int, c_int, c_int, u16p, c_int, c_int, c_int, u16p, f32p, f32p, c_float,
                                     f32p, f32p, u16p, c_int])
     _sig(lib, "q3t_talker_sample", c_int, [f32p, c_int, i32p, c_int, c_int, c_int])
+    _sig(lib, "q3t_set_linear_split_rows", c_int, [c_int])
     _sig(lib, "q3t_bench_linear", c_float, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int])
     if path is None:
         _lib = lib
