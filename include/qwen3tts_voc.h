@@ -1,0 +1,54 @@
+/*
+ * qwen3tts_voc.h -- C ABI of the MI355X vocoder library (codec ids -> 24 kHz waveform, fp32).
+ *
+ * The reference has no C ABI here: dual_npu/vocoder_server.py:67-71 calls onnxruntime
+ * (`sess.run(None, {'audio_codes': i64[1,64,16]})[0].flatten()`), the graph being the traced
+ * Qwen3TTSTokenizerV2 decoder of scripts/export_vocoder_traced.py:38-52 (input [B,T,16] int64,
+ * permuted to [B,16,T]; output wav.squeeze(1), length T * total_upsample = T * 1920).  voc_decode
+ * is that call; voc_synthesize is VocoderServer.synthesize + the int16 rule
+ * (vocoder_server.py:73-121,175) including its chunk-length quirk.
+ *
+ * The decoder's layer list is NOT in the reference: the library executes
+ * the op table stored in the weight container (`voc.program`, DESIGN.md "Vocoder program"), so a
+ * real checkpoint only needs converting, not a rebuild.
+ *
+ * Caller-owned host buffers, synchronous, one caller thread per handle, no CPU fallback.
+ */
+#ifndef QWEN3TTS_VOC_H
+#define QWEN3TTS_VOC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define Q3VOC_SAMPLES_PER_TOKEN 1920 /* vocoder_server.py:30 */
+#define Q3VOC_SAMPLE_RATE 24000      /* vocoder_server.py:29 */
+
+/* weights: Q3TTSW1 container holding voc.*.  chunk_tokens: frames per decode call (the ONNX model's
+ * fixed input length, 64 in the reference: vocoder_server.py:45-46); max_batch chunks per call. */
+void* voc_load(const char* weights, int chunk_tokens, int max_batch);
+void voc_free(void* v);
+int voc_chunk_tokens(void* v);
+int voc_samples_per_token(void* v);
+
+/* codes[B][chunk_tokens][16] int64 (ids 0..2047; out-of-range ids embed as zeros) ->
+ * out[B][chunk_tokens*1920] f32 in [-1, 1].  0 ok / <0 error. */
+int voc_decode(void* v, const int64_t* codes, int B, float* out);
+
+/* VocoderServer.synthesize + int16 conversion for one utterance: codes[n][16] -> out samples.
+ * out must hold voc_synthesize_max_samples(n) int16.  Returns 0 and *n_samples, or <0. */
+int voc_synthesize(void* v, const int64_t* codes, int n_tokens, int16_t* out, int32_t* n_samples);
+/* same, float output before the int16 rule */
+int voc_synthesize_f32(void* v, const int64_t* codes, int n_tokens, float* out, int32_t* n_samples);
+int voc_synthesize_max_samples(void* v, int n_tokens);
+
+/* GPU milliseconds of the last voc_decode (HIP events on the library's stream) and its FLOP count. */
+float voc_last_decode_ms(void* v);
+double voc_decode_flops(void* v, int B);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QWEN3TTS_VOC_H */

@@ -1,0 +1,561 @@
+// q3_voc.hip -- fp32 vocoder (codec ids -> waveform) for gfx950, include/qwen3tts_voc.h.
+//
+// Stands where the reference calls onnxruntime on the traced Qwen3TTSTokenizerV2 decoder
+// (dual_npu/vocoder_server.py:67-71; scripts/export_vocoder_traced.py:38-52).  The decoder's layer
+// list is not in the reference, so the library interprets an op table from the weight container
+// (tensor `voc.program`, int32 [n_ops][8]); DESIGN.md documents the table and the default one
+// (split-RVQ de-quantiser -> causal conv -> x2 x2 transposed-conv upsamplers -> BigVGAN-style
+// decoder: rates 8,5,4,3, residual units with dilations 1,3,9, Snake activations).
+//
+// Kernels:
+//   rvq_kernel     16 codebook gathers per frame, summed per quantiser half, two 256->512 projections
+//   conv_kernel    causal Conv1d / polyphase ConvTranspose1d as an implicit GEMM on the exact-fp32 MFMA
+//                  (v_mfma_f32_32x32x2_f32): one input tile [8 ch][128+halo] is staged once in LDS (the
+//                  line buffer) and read at every dilated tap offset; Snake is applied while staging,
+//                  bias / residual add / clamp in the epilogue.
+#include "../../include/qwen3tts_voc.h"
+#include "q3_common.h"
+
+#include <cmath>
+
+namespace q3 {
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+enum { VOP_RVQ = 1, VOP_CONV = 2, VOP_CONVT = 3 };
+enum { VF_SNAKE = 1, VF_RES_ADD = 2, VF_RES_SAVE = 4, VF_CLAMP = 8 };
+
+struct ConvArgs {
+    const float* x = nullptr;   // [B][Cin][Lin]
+    float* y = nullptr;         // [B][Cout][Lin*stride]
+    const float* wk = nullptr;  // [K][M][Cin], M = Cout*stride virtual rows
+    const float* bias = nullptr;
+    const float* alpha = nullptr;     // [Cin] Snake: x + inv_beta * sin^2(alpha x), applied to the input
+    const float* inv_beta = nullptr;
+    const float* res = nullptr;       // [B][Cout][L] added in the epilogue
+    int Cin = 0, M = 0, K = 0, dil = 1, Lin = 0, stride = 1, Cout = 0, clamp = 0;
+};
+
+constexpr int VKC = 8;     // input channels per LDS stage
+constexpr int VTN = 128;   // output columns per workgroup (4 waves x 32)
+
+template <int MT>
+__global__ void __launch_bounds__(256) conv_kernel(ConvArgs a) {
+    constexpr int TM = 32 * MT, TMP = TM + 4;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l0 = blockIdx.x * VTN, m0 = blockIdx.y * TM, b = blockIdx.z;
+    const int halo = (a.K - 1) * a.dil;
+    const int XW = VTN + halo;  // staged columns: l0-halo .. l0+127
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Ws = lds;                      // [K][VKC][TMP]
+    float* Xs = lds + a.K * VKC * TMP;    // [VKC][XW]
+    const float* xb = a.x + (size_t)b * a.Cin * a.Lin;
+
+    f16v acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[mt][i] = 0.f;
+
+    for (int ci0 = 0; ci0 < a.Cin; ci0 += VKC) {
+        __syncthreads();  // previous stage fully consumed
+        // weights of all K taps for this channel slice: global [k][m][ci] (8 contiguous ci) -> Ws[k][ci][m]
+        for (int idx = tid; idx < a.K * TM * 2; idx += 256) {
+            const int half = idx & 1, mm = (idx >> 1) % TM, k = (idx >> 1) / TM;
+            const int m = m0 + mm;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < a.M) v = *(const float4*)(a.wk + ((size_t)k * a.M + m) * a.Cin + ci0 + half * 4);
+            float* d = Ws + (k * VKC + half * 4) * TMP + mm;
+            d[0] = v.x;
+            d[TMP] = v.y;
+            d[2 * TMP] = v.z;
+            d[3 * TMP] = v.w;
+        }
+        // the input line buffer (causal: columns left of 0 are zero; Snake(0) = 0 so padding commutes)
+        for (int idx = tid; idx < VKC * XW; idx += 256) {
+            const int ci = idx / XW, col = idx % XW;
+            const int l = l0 - halo + col;
+            float v = 0.f;
+            if (l >= 0 && l < a.Lin) {
+                v = xb[(size_t)(ci0 + ci) * a.Lin + l];
+                if (a.alpha) {
+                    const float sn = sinf(a.alpha[ci0 + ci] * v);
+                    v = v + a.inv_beta[ci0 + ci] * (sn * sn);
+                }
+            }
+            Xs[ci * XW + col] = v;
+        }
+        __syncthreads();
+        for (int k = 0; k < a.K; k++) {
+            const int off = halo - (a.K - 1 - k) * a.dil + w * 32 + (lane & 31);
+#pragma unroll
+            for (int kk = 0; kk < VKC; kk += 2) {
+                const int ci = kk + (lane >> 5);
+                const float bv = Xs[ci * XW + off];
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    const float av = Ws[(k * VKC + ci) * TMP + mt * 32 + (lane & 31)];
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // epilogue.  D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int l = l0 + w * 32 + (lane & 31);
+    const int Lout = a.Lin * a.stride;
+    if (l < a.Lin) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < a.M) {
+                    const int co = a.stride == 1 ? m : m / a.stride;
+                    const int p = a.stride == 1 ? 0 : m % a.stride;
+                    const size_t idx = ((size_t)b * a.Cout + co) * Lout + (size_t)l * a.stride + p;
+                    float v = acc[mt][r];
+                    if (a.bias) v += a.bias[co];
+                    if (a.res) v += a.res[idx];
+                    if (a.clamp) v = fminf(fmaxf(v, -1.f), 1.f);
+                    a.y[idx] = v;
+                }
+            }
+    }
+}
+
+template <int MT>
+static int launch_conv_t(hipStream_t s, const ConvArgs& a, int B) {
+    constexpr int TM = 32 * MT, TMP = TM + 4;
+    const int halo = (a.K - 1) * a.dil;
+    const size_t lds = ((size_t)a.K * VKC * TMP + (size_t)VKC * (VTN + halo)) * sizeof(float);
+    static size_t attr = 0;
+    if (lds > attr && lds > 48 * 1024) {
+        Q3_HIP(hipFuncSetAttribute((const void*)conv_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256), -1);
+        attr = 160 * 1024;
+    }
+    dim3 grid((a.Lin + VTN - 1) / VTN, (a.M + TM - 1) / TM, B);
+    hipLaunchKernelGGL((conv_kernel<MT>), grid, dim3(256), lds, s, a);
+    Q3_HIP(hipGetLastError(), -1);
+    return 0;
+}
+
+static int launch_conv(hipStream_t s, const ConvArgs& a, int B) {
+    if (a.Cin % VKC) {
+        Q3_LOG("voc conv: Cin=%d is not a multiple of %d", a.Cin, VKC);
+        return -1;
+    }
+    const int t32 = (a.M + 31) / 32;  // 32-row MFMA tiles needed
+    int mt = 4;
+    if (t32 % 4 != 0) mt = (t32 % 3 == 0) ? 3 : (t32 % 2 == 0) ? 2 : (t32 < 4 ? t32 : 4);
+    switch (mt) {
+        case 1: return launch_conv_t<1>(s, a, B);
+        case 2: return launch_conv_t<2>(s, a, B);
+        case 3: return launch_conv_t<3>(s, a, B);
+        default: return launch_conv_t<4>(s, a, B);
+    }
+}
+
+// Split residual VQ de-quantisation: codes i64 [B][T][NQ] -> y [B][OUT][T].
+// Quantiser 0 (semantic) and 1..NQ-1 (acoustic) each sum their codebook rows ([NQ][CB][DIM]) and go
+// through their own DIM->OUT projection (1x1 conv without bias); the two results add.
+__global__ void __launch_bounds__(256) rvq_kernel(const int64_t* __restrict__ codes, const float* __restrict__ cb,
+                                                  const float* __restrict__ p_sem, const float* __restrict__ p_ac,
+                                                  float* __restrict__ y, int T, int NQ, int CB, int DIM, int OUT) {
+    extern __shared__ float e[];  // [2][DIM]
+    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int64_t* c = codes + ((size_t)b * T + t) * NQ;
+    for (int d = tid; d < DIM; d += blockDim.x) {
+        float s0 = 0.f, s1 = 0.f;
+        const int64_t c0 = c[0];
+        if (c0 >= 0 && c0 < CB) s0 = cb[((size_t)0 * CB + c0) * DIM + d];
+        for (int q = 1; q < NQ; q++) {
+            const int64_t cq = c[q];
+            if (cq >= 0 && cq < CB) s1 += cb[((size_t)q * CB + cq) * DIM + d];
+        }
+        e[d] = s0;
+        e[DIM + d] = s1;
+    }
+    __syncthreads();
+    for (int o = tid; o < OUT; o += blockDim.x) {
+        float acc = 0.f;
+        for (int d = 0; d < DIM; d++) acc += p_sem[(size_t)o * DIM + d] * e[d];
+        for (int d = 0; d < DIM; d++) acc += p_ac[(size_t)o * DIM + d] * e[DIM + d];
+        y[((size_t)b * OUT + o) * T + t] = acc;
+    }
+}
+
+struct VocOp {
+    int op = 0, cin = 0, cout = 0, k = 0, p0 = 0, flags = 0, nq = 0, cb = 0;
+    float *w = nullptr, *bias = nullptr, *alpha = nullptr, *inv_beta = nullptr;  // device
+    float *p_sem = nullptr, *p_ac = nullptr;
+};
+
+struct Voc {
+    int chunk = 64, max_batch = 1, upsample = 1;
+    std::vector<VocOp> ops;
+    std::vector<void*> allocs;
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int64_t* d_codes = nullptr;
+    float *buf[3] = {nullptr, nullptr, nullptr};
+    size_t buf_elems = 0;
+    float last_ms = 0.f;
+    double flops_per_chunk = 0.0;
+    std::vector<float> h_chunk;
+};
+
+static float* voc_up(Voc* v, const PackTensor* t) {
+    size_t ne = t->numel();
+    std::vector<float> tmp;
+    const float* src = (const float*)t->data;
+    if (t->dtype == F16) {
+        tmp.resize(ne);
+        for (size_t i = 0; i < ne; i++) tmp[i] = h2f(((const uint16_t*)t->data)[i]);
+        src = tmp.data();
+    } else if (t->dtype != F32) {
+        return nullptr;
+    }
+    float* d = nullptr;
+    if (hipMalloc((void**)&d, ne * 4) != hipSuccess) return nullptr;
+    v->allocs.push_back(d);
+    if (hipMemcpy(d, src, ne * 4, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return d;
+}
+
+static float* voc_up_host(Voc* v, const std::vector<float>& h) {
+    float* d = nullptr;
+    if (hipMalloc((void**)&d, h.size() * 4) != hipSuccess) return nullptr;
+    v->allocs.push_back(d);
+    if (hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return d;
+}
+
+static void voc_destroy(Voc* v) {
+    if (!v) return;
+    if (v->s) hipStreamSynchronize(v->s);
+    for (void* p : v->allocs) hipFree(p);
+    for (float* b : v->buf)
+        if (b) hipFree(b);
+    if (v->d_codes) hipFree(v->d_codes);
+    if (v->e0) hipEventDestroy(v->e0);
+    if (v->e1) hipEventDestroy(v->e1);
+    if (v->s) hipStreamDestroy(v->s);
+    delete v;
+}
+
+}  // namespace q3
+
+using namespace q3;
+
+extern "C" {
+
+void voc_free(void* vv) { voc_destroy((Voc*)vv); }
+
+void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        Q3_LOG("no HIP device available -- this library has no CPU path");
+        return nullptr;
+    }
+    if (!weights) return nullptr;
+    Pack p;
+    if (!p.open(weights)) return nullptr;
+    const PackTensor* prog = p.find("voc.program");
+    if (!prog || prog->dtype != I32 || prog->ndim != 2 || prog->shape[1] != 8) {
+        Q3_LOG("%s holds no vocoder program (tensor voc.program int32 [n][8])", weights);
+        return nullptr;
+    }
+    Voc* v = new Voc();
+    v->chunk = chunk_tokens > 0 ? chunk_tokens : 64;
+    v->max_batch = max_batch > 0 ? max_batch : 1;
+    bool ok = hipStreamCreateWithFlags(&v->s, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreate(&v->e0) == hipSuccess && hipEventCreate(&v->e1) == hipSuccess;
+    const int32_t* pr = (const int32_t*)prog->data;
+    const int n_ops = (int)prog->shape[0];
+    int C = 0;
+    long L = v->chunk;
+    size_t max_elems = 0;
+    double flops = 0.0;
+    for (int i = 0; i < n_ops && ok; i++) {
+        const int32_t* r = pr + i * 8;
+        VocOp op;
+        op.op = r[0];
+        const std::string base = "voc.op" + std::to_string(i) + ".";
+        auto need = [&](const char* n) -> const PackTensor* {
+            const PackTensor* t = p.find(base + n);
+            if (!t) {
+                Q3_LOG("vocoder program op %d needs tensor %s%s", i, base.c_str(), n);
+                ok = false;
+            }
+            return t;
+        };
+        if (op.op == VOP_RVQ) {
+            op.nq = r[1];
+            op.cb = r[2];
+            op.cin = r[3];   // codebook dim
+            op.cout = r[4];  // output channels
+            const PackTensor *cb = need("codebook"), *ps = need("proj_sem"), *pa = need("proj_ac");
+            if (!ok) break;
+            if (cb->numel() != (uint64_t)op.nq * op.cb * op.cin || ps->numel() != (uint64_t)op.cout * op.cin ||
+                pa->numel() != (uint64_t)op.cout * op.cin) {
+                Q3_LOG("vocoder op %d: RVQ tensor sizes do not match the program", i);
+                ok = false;
+                break;
+            }
+            op.w = voc_up(v, cb);
+            op.p_sem = voc_up(v, ps);
+            op.p_ac = voc_up(v, pa);
+            ok = op.w && op.p_sem && op.p_ac;
+            C = op.cout;
+            flops += 2.0 * 2 * op.cin * op.cout * L;
+        } else if (op.op == VOP_CONV || op.op == VOP_CONVT) {
+            op.cin = r[1];
+            op.cout = r[2];
+            op.k = r[3];
+            op.p0 = r[4];  // dilation (conv) or stride (convT)
+            op.flags = r[5];
+            if (op.cin != C) {
+                Q3_LOG("vocoder op %d: expects %d input channels, previous op produced %d", i, op.cin, C);
+                ok = false;
+                break;
+            }
+            const PackTensor *wt = need("weight"), *bs = p.find(base + "bias");
+            if (!ok) break;
+            if (wt->numel() != (uint64_t)op.cin * op.cout * op.k || wt->dtype != F32) {
+                Q3_LOG("vocoder op %d: weight size/dtype does not match the program", i);
+                ok = false;
+                break;
+            }
+            // repack to [tap][row][cin]
+            const float* src = (const float*)wt->data;
+            std::vector<float> wk;
+            if (op.op == VOP_CONV) {  // torch Conv1d weight [cout][cin][k]
+                wk.resize((size_t)op.k * op.cout * op.cin);
+                for (int co = 0; co < op.cout; co++)
+                    for (int ci = 0; ci < op.cin; ci++)
+                        for (int k = 0; k < op.k; k++)
+                            wk[((size_t)k * op.cout + co) * op.cin + ci] = src[((size_t)co * op.cin + ci) * op.k + k];
+            } else {  // torch ConvTranspose1d weight [cin][cout][k], k = J*stride: polyphase rows m = co*s + p,
+                      // tap j (input offset -j) reads w[ci][co][p + j*s]; conv tap index kk = J-1-j.  Causal:
+                      // the first Lin*s outputs are kept (the k-s trailing ones are trimmed).
+                const int s = op.p0;
+                const int J = s > 0 ? op.k / s : 0;
+                if (s <= 0 || J < 1 || op.k != J * s) {
+                    Q3_LOG("vocoder op %d: transposed conv needs kernel = J*stride (got k=%d s=%d)", i, op.k, s);
+                    ok = false;
+                    break;
+                }
+                wk.resize((size_t)J * op.cout * s * op.cin);
+                for (int j = 0; j < J; j++)
+                    for (int co = 0; co < op.cout; co++)
+                        for (int ph = 0; ph < s; ph++)
+                            for (int ci = 0; ci < op.cin; ci++)
+                                wk[((size_t)(J - 1 - j) * op.cout * s + (size_t)co * s + ph) * op.cin + ci] =
+                                    src[((size_t)ci * op.cout + co) * op.k + ph + j * s];
+            }
+            op.w = voc_up_host(v, wk);
+            op.bias = bs ? voc_up(v, bs) : nullptr;
+            if (op.flags & VF_SNAKE) {
+                const PackTensor *al = need("alpha"), *be = need("beta");
+                if (!ok) break;
+                // SnakeBeta with log-scale parameters: x + sin^2(exp(a) x) / (exp(b) + 1e-9)
+                std::vector<float> ha(op.cin), hb(op.cin);
+                for (int c = 0; c < op.cin; c++) {
+                    const float av = al->dtype == F32 ? ((const float*)al->data)[c] : h2f(((const uint16_t*)al->data)[c]);
+                    const float bv = be->dtype == F32 ? ((const float*)be->data)[c] : h2f(((const uint16_t*)be->data)[c]);
+                    ha[c] = expf(av);
+                    hb[c] = 1.0f / (expf(bv) + 1e-9f);
+                }
+                op.alpha = voc_up_host(v, ha);
+                op.inv_beta = voc_up_host(v, hb);
+            }
+            ok = ok && op.w;
+            flops += 2.0 * op.cin * op.cout * op.k * L;  // per input column; convT: k taps spread over s outputs
+            C = op.cout;
+            if (op.op == VOP_CONVT) L *= op.p0;
+        } else {
+            Q3_LOG("vocoder program op %d: unknown opcode %d", i, op.op);
+            ok = false;
+            break;
+        }
+        if ((size_t)C * L > max_elems) max_elems = (size_t)C * L;
+        v->ops.push_back(op);
+    }
+    if (ok && (C != 1 || L % v->chunk != 0)) {
+        Q3_LOG("vocoder program must end with 1 channel (got %d)", C);
+        ok = false;
+    }
+    if (ok) {
+        v->upsample = (int)(L / v->chunk);
+        v->flops_per_chunk = flops;
+        v->buf_elems = max_elems * v->max_batch;
+        for (int i = 0; i < 3 && ok; i++) ok = hipMalloc((void**)&v->buf[i], v->buf_elems * 4) == hipSuccess;
+        ok = ok && hipMalloc((void**)&v->d_codes, sizeof(int64_t) * 16 * v->chunk * v->max_batch) == hipSuccess;
+    }
+    if (!ok) {
+        Q3_LOG("voc_load failed");
+        voc_destroy(v);
+        return nullptr;
+    }
+    v->h_chunk.resize((size_t)v->chunk * v->upsample);
+    return v;
+}
+
+int voc_chunk_tokens(void* vv) { return vv ? ((Voc*)vv)->chunk : 0; }
+int voc_samples_per_token(void* vv) { return vv ? ((Voc*)vv)->upsample : 0; }
+float voc_last_decode_ms(void* vv) { return vv ? ((Voc*)vv)->last_ms : -1.f; }
+double voc_decode_flops(void* vv, int B) { return vv ? ((Voc*)vv)->flops_per_chunk * B : 0.0; }
+
+static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = nullptr, long* outL = nullptr) {
+    // ping-pong between buf[0]/buf[1]; buf[2] keeps the residual-unit input
+    int cur = 0;
+    int C = 0;
+    long L = v->chunk;
+    float* res = nullptr;
+    const size_t nrun = n_ops < 0 ? v->ops.size() : (size_t)n_ops < v->ops.size() ? (size_t)n_ops : v->ops.size();
+    for (size_t i = 0; i < nrun; i++) {
+        const VocOp& op = v->ops[i];
+        float* in = v->buf[cur];
+        float* out = v->buf[cur ^ 1];
+        if (op.op == VOP_RVQ) {
+            hipLaunchKernelGGL(rvq_kernel, dim3(v->chunk, B), dim3(256), 2 * op.cin * sizeof(float), v->s, v->d_codes, op.w,
+                               op.p_sem, op.p_ac, out, v->chunk, op.nq, op.cb, op.cin, op.cout);
+            Q3_HIP(hipGetLastError(), -1);
+            C = op.cout;
+        } else {
+            ConvArgs a;
+            a.x = in;
+            a.y = out;
+            a.wk = op.w;
+            a.bias = op.bias;
+            a.alpha = op.alpha;
+            a.inv_beta = op.inv_beta;
+            a.Cin = op.cin;
+            a.Cout = op.cout;
+            a.Lin = (int)L;
+            a.clamp = (op.flags & VF_CLAMP) ? 1 : 0;
+            if (op.op == VOP_CONV) {
+                a.K = op.k;
+                a.dil = op.p0;
+                a.stride = 1;
+                a.M = op.cout;
+            } else {
+                a.K = op.k / op.p0;
+                a.dil = 1;
+                a.stride = op.p0;
+                a.M = op.cout * op.p0;
+            }
+            if (op.flags & VF_RES_SAVE) {
+                // the unit's input is needed again after two convs: keep it where the ping-pong will not write
+                Q3_HIP(hipMemcpyAsync(v->buf[2], in, sizeof(float) * (size_t)B * C * L, hipMemcpyDeviceToDevice, v->s), -1);
+                res = v->buf[2];
+            }
+            if (op.flags & VF_RES_ADD) a.res = res;
+            if (launch_conv(v->s, a, B)) return -1;
+            C = op.cout;
+            if (op.op == VOP_CONVT) L *= op.p0;
+        }
+        cur ^= 1;
+    }
+    *out_dev = v->buf[cur];
+    if (outC) *outC = C;
+    if (outL) *outL = L;
+    return 0;
+}
+
+int voc_decode(void* vv, const int64_t* codes, int B, float* out) {
+    Voc* v = (Voc*)vv;
+    if (!v || !codes || !out || B <= 0 || B > v->max_batch) return -1;
+    Q3_HIP(hipMemcpyAsync(v->d_codes, codes, sizeof(int64_t) * 16 * (size_t)v->chunk * B, hipMemcpyHostToDevice, v->s), -1);
+    Q3_HIP(hipEventRecord(v->e0, v->s), -1);
+    float* res = nullptr;
+    if (voc_run(v, B, &res)) return -1;
+    Q3_HIP(hipEventRecord(v->e1, v->s), -1);
+    Q3_HIP(hipMemcpyAsync(out, res, sizeof(float) * (size_t)B * v->chunk * v->upsample, hipMemcpyDeviceToHost, v->s), -1);
+    Q3_HIP(hipStreamSynchronize(v->s), -1);
+    hipEventElapsedTime(&v->last_ms, v->e0, v->e1);
+    return 0;
+}
+
+// test hook: run only the first n_ops ops, return the activation [B][C][L]
+int voc_debug_run(void* vv, const int64_t* codes, int B, int n_ops, float* out, int* C, int* L) {
+    Voc* v = (Voc*)vv;
+    if (!v || B <= 0 || B > v->max_batch) return -1;
+    Q3_HIP(hipMemcpyAsync(v->d_codes, codes, sizeof(int64_t) * 16 * (size_t)v->chunk * B, hipMemcpyHostToDevice, v->s), -1);
+    float* res = nullptr;
+    long LL = 0;
+    if (voc_run(v, B, &res, n_ops, C, &LL)) return -1;
+    *L = (int)LL;
+    Q3_HIP(hipMemcpyAsync(out, res, sizeof(float) * (size_t)B * (*C) * LL, hipMemcpyDeviceToHost, v->s), -1);
+    Q3_HIP(hipStreamSynchronize(v->s), -1);
+    return 0;
+}
+
+int voc_synthesize_max_samples(void* vv, int n) {
+    Voc* v = (Voc*)vv;
+    if (!v || n <= 0) return 0;
+    return (n + v->chunk) * v->upsample;  // the reference's redundant tail chunk adds < chunk frames
+}
+
+// VocoderServer.synthesize (vocoder_server.py:73-121), bug-compatible chunk walk, float output.
+int voc_synthesize_f32(void* vv, const int64_t* codes, int n, float* out, int32_t* n_samples) {
+    Voc* v = (Voc*)vv;
+    if (!v || !codes || !out || !n_samples || n <= 0) return -1;
+    const int CH = v->chunk, SPT = v->upsample;
+    std::vector<int64_t> padded((size_t)CH * 16);
+    std::vector<float>& chunk = v->h_chunk;
+    auto run_chunk = [&](int start, int len) -> int {
+        std::fill(padded.begin(), padded.end(), 0);
+        memcpy(padded.data(), codes + (size_t)start * 16, sizeof(int64_t) * 16 * len);
+        return voc_decode(v, padded.data(), 1, chunk.data());
+    };
+    if (n <= CH) {
+        if (run_chunk(0, n)) return -1;
+        memcpy(out, chunk.data(), sizeof(float) * (size_t)n * SPT);
+        *n_samples = n * SPT;
+        return 0;
+    }
+    const int OVERLAP = 16, OV = OVERLAP * SPT, step = CH - OVERLAP;
+    size_t have = 0;
+    for (int start = 0; start < n; start += step) {
+        const int len = (start + CH <= n) ? CH : n - start;
+        if (run_chunk(start, len)) return -1;
+        const size_t cl = (size_t)len * SPT;
+        if (start == 0) {
+            memcpy(out, chunk.data(), sizeof(float) * cl);
+            have = cl;
+        } else if (have >= (size_t)OV && cl >= (size_t)OV) {
+            // np.linspace(1, 0, OV, dtype=float32) fade-out, fade-in = 1 - fade-out, blended in float32
+            float* tail = out + have - OV;
+            for (int i = 0; i < OV; i++) {
+                const double stepv = -1.0 / (double)(OV - 1);
+                const float fo = (i == OV - 1) ? 0.0f : (float)(1.0 + (double)i * stepv);
+                const float fi = 1.0f - fo;
+                tail[i] = tail[i] * fo + chunk[i] * fi;
+            }
+            memcpy(out + have, chunk.data() + OV, sizeof(float) * (cl - OV));
+            have += cl - OV;
+        } else {
+            memcpy(out + have, chunk.data(), sizeof(float) * cl);
+            have += cl;
+        }
+    }
+    *n_samples = (int32_t)have;
+    return 0;
+}
+
+int voc_synthesize(void* vv, const int64_t* codes, int n, int16_t* out, int32_t* n_samples) {
+    Voc* v = (Voc*)vv;
+    if (!v || !out) return -1;
+    std::vector<float> f((size_t)voc_synthesize_max_samples(v, n));
+    if (voc_synthesize_f32(v, codes, n, f.data(), n_samples)) return -1;
+    for (int32_t i = 0; i < *n_samples; i++) {
+        // np.clip(audio * 32767, -32768, 32767).astype(np.int16): float32 product, truncation toward zero
+        float x = f[i] * 32767.0f;
+        x = x < -32768.0f ? -32768.0f : (x > 32767.0f ? 32767.0f : x);
+        out[i] = (int16_t)x;
+    }
+    return 0;
+}
+
+}  // extern "C"

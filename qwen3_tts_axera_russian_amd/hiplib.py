@@ -69,6 +69,17 @@ def load(path: str | None = None):
     _sig(lib, "q3e_get_codes", c_int, [c_void_p, i32p, c_int, i32p])
     _sig(lib, "q3e_get_hidden", c_int, [c_void_p, f32p])
     _sig(lib, "q3e_step_weight_bytes", ctypes.c_double, [c_void_p])
+    # include/qwen3tts_voc.h
+    _sig(lib, "voc_load", c_void_p, [c_char_p, c_int, c_int])
+    _sig(lib, "voc_free", None, [c_void_p])
+    _sig(lib, "voc_chunk_tokens", c_int, [c_void_p])
+    _sig(lib, "voc_samples_per_token", c_int, [c_void_p])
+    _sig(lib, "voc_decode", c_int, [c_void_p, i64p, c_int, f32p])
+    _sig(lib, "voc_synthesize", c_int, [c_void_p, i64p, c_int, i16p, i32p])
+    _sig(lib, "voc_synthesize_f32", c_int, [c_void_p, i64p, c_int, f32p, i32p])
+    _sig(lib, "voc_synthesize_max_samples", c_int, [c_void_p, c_int])
+    _sig(lib, "voc_last_decode_ms", c_float, [c_void_p])
+    _sig(lib, "voc_decode_flops", ctypes.c_double, [c_void_p, c_int])
     # test hooks
     _sig(lib, "q3t_device_count", c_int, [])
     _sig(lib, "q3_set_device", c_int, [c_int])

@@ -326,3 +326,108 @@ def from_hf_checkpoint(model_dir: str, out_path: str, cfg: ModelConfig | None = 
         t[f"text.{fc}.weight"] = f32(f"talker.text_projection.linear_{fc}.weight")
         t[f"text.{fc}.bias"] = f32(f"talker.text_projection.linear_{fc}.bias")
     write_pack(out_path, cfg.meta(), t)
+
+
+# ----------------------------------------------------------------------------
+# vocoder program (include/qwen3tts_voc.h, csrc/q3_voc.hip)
+# ----------------------------------------------------------------------------
+VOP_RVQ, VOP_CONV, VOP_CONVT = 1, 2, 3
+VF_SNAKE, VF_RES_ADD, VF_RES_SAVE, VF_CLAMP = 1, 2, 4, 8
+
+
+@dataclass
+class VocConfig:
+    """Shape of the codec decoder.  The reference does not contain it; the
+    defaults follow the published Qwen3-TTS-Tokenizer-12Hz decoder as far as it is known here:
+    16 codebooks x 2048 entries (split RVQ: 1 semantic + 15 acoustic, dim 256 -> 512), causal conv
+    to the latent width, two x2 transposed-conv upsamplers, then a BigVGAN-style stack with rates
+    8,5,4,3 (2*2*8*5*4*3 = 1920 samples per frame) whose residual units use dilations 1,3,9 and
+    Snake activations.  The pre-transformer and the ConvNeXt blocks of the published model are not
+    in this table yet ("Vocoder program")."""
+    n_q: int = 16
+    codebook_size: int = 2048
+    codebook_dim: int = 256
+    rvq_out: int = 512
+    latent: int = 1024
+    pre_kernel: int = 3
+    upsample_ratios: tuple = (2, 2)
+    decoder_dim: int = 1536
+    rates: tuple = (8, 5, 4, 3)
+    dilations: tuple = (1, 3, 9)
+    kernel: int = 7
+
+
+def tiny_voc_config() -> VocConfig:
+    return VocConfig(codebook_dim=32, rvq_out=64, latent=64, decoder_dim=128)
+
+
+def voc_program(vc: VocConfig):
+    """-> list of (op, a, b, c, d, flags) rows + per-op tensor shapes."""
+    prog, shapes = [], {}
+
+    def add(row, tens):
+        i = len(prog)
+        prog.append(list(row) + [0] * (8 - len(row)))
+        for n, shp in tens.items():
+            shapes[f"voc.op{i}.{n}"] = shp
+
+    add([VOP_RVQ, vc.n_q, vc.codebook_size, vc.codebook_dim, vc.rvq_out],
+        {"codebook": (vc.n_q, vc.codebook_size, vc.codebook_dim), "proj_sem": (vc.rvq_out, vc.codebook_dim),
+         "proj_ac": (vc.rvq_out, vc.codebook_dim)})
+
+    def conv(cin, cout, k, dil, flags):
+        t = {"weight": (cout, cin, k), "bias": (cout,)}
+        if flags & VF_SNAKE:
+            t.update({"alpha": (cin,), "beta": (cin,)})
+        add([VOP_CONV, cin, cout, k, dil, flags], t)
+
+    def convt(cin, cout, k, stride, flags):
+        t = {"weight": (cin, cout, k), "bias": (cout,)}
+        if flags & VF_SNAKE:
+            t.update({"alpha": (cin,), "beta": (cin,)})
+        add([VOP_CONVT, cin, cout, k, stride, flags], t)
+
+    conv(vc.rvq_out, vc.latent, vc.pre_kernel, 1, 0)
+    for f in vc.upsample_ratios:
+        convt(vc.latent, vc.latent, f, f, 0)
+    conv(vc.latent, vc.decoder_dim, vc.kernel, 1, 0)
+    c = vc.decoder_dim
+    for r in vc.rates:
+        convt(c, c // 2, 2 * r, r, VF_SNAKE)
+        c //= 2
+        for d in vc.dilations:
+            conv(c, c, vc.kernel, d, VF_SNAKE | VF_RES_SAVE)
+            conv(c, c, 1, 1, VF_SNAKE | VF_RES_ADD)
+    conv(c, 1, vc.kernel, 1, VF_SNAKE | VF_CLAMP)
+    return prog, shapes
+
+
+def make_synthetic_voc(vc: VocConfig, seed: int = 1234) -> dict:
+    prog, shapes = voc_program(vc)
+    t = {"voc.program": np.asarray(prog, dtype=np.int32)}
+    for n, shp in shapes.items():
+        rng = _rng_for(n, seed)
+        if n.endswith(("alpha", "beta")):
+            a = 0.3 * rng.standard_normal(shp, dtype=np.float32)
+        elif n.endswith("bias"):
+            a = 0.02 * rng.standard_normal(shp, dtype=np.float32)
+        elif n.endswith("codebook"):
+            a = 0.25 * rng.standard_normal(shp, dtype=np.float32)
+        else:
+            fan_in = int(np.prod(shp[1:])) if not n.endswith(("proj_sem", "proj_ac")) else shp[1]
+            if ".weight" in n and len(shp) == 3 and prog[int(n.split(".")[1][2:])][0] == VOP_CONVT:
+                fan_in = shp[0] * max(1, shp[2] // prog[int(n.split(".")[1][2:])][4])
+            # gains < 1 keep the random stack contractive (activations O(1), like a trained decoder);
+            # the 1x1 conv that closes a residual unit is damped further
+            row = prog[int(n.split(".")[1][2:])]
+            gain = 0.25 if (".weight" in n and row[0] == VOP_CONV and row[3] == 1 and (row[5] & VF_RES_ADD)) else 0.7
+            a = (gain * rng.standard_normal(shp, dtype=np.float32) / np.sqrt(fan_in)).astype(np.float32)
+        t[n] = a.astype(np.float32)
+    return t
+
+
+def voc_total_upsample(vc: VocConfig) -> int:
+    u = 1
+    for f in tuple(vc.upsample_ratios) + tuple(vc.rates):
+        u *= f
+    return u

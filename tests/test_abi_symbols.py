@@ -1,0 +1,54 @@
+"""The shared library loads without a GPU and exports every symbol include/*.h declares
+(no compute calls here).  CPU only."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from qwen3_tts_axera_russian_amd import build
+    return ctypes.CDLL(build.build())
+
+
+def _declared(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:wrapper|cp|voc|q3e)_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.mark.parametrize("header", ["qwen3tts_talker.h", "qwen3tts_cp.h", "qwen3tts_voc.h", "qwen3tts_engine.h"])
+def test_every_declared_symbol_is_exported(lib, header):
+    names = _declared(header)
+    assert len(names) >= 5
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_reference_wrapper_names_present(lib):
+    # the 12 entry points of dual_npu/llama_wrapper.c, bound by llama_cpp_bindings.py:41-81
+    ref = ["wrapper_backend_init", "wrapper_backend_free", "wrapper_load_model", "wrapper_free_model",
+           "wrapper_model_n_embd", "wrapper_create_context", "wrapper_free_context", "wrapper_kv_clear",
+           "wrapper_decode_embd", "wrapper_state_get_size", "wrapper_state_save_file", "wrapper_state_load_file"]
+    assert all(hasattr(lib, n) for n in ref)
+    alias = os.path.join(ROOT, "qwen3_tts_axera_russian_amd", "lib", "llama_wrapper.so")
+    assert os.path.exists(alias)  # the name llama_cpp_bindings.py:18-21 looks for
+
+
+def test_fails_loudly_without_gpu_or_weights(lib, tmp_path):
+    lib.wrapper_load_model.restype = ctypes.c_void_p
+    lib.cp_load.restype = ctypes.c_void_p
+    lib.voc_load.restype = ctypes.c_void_p
+    lib.q3e_create.restype = ctypes.c_void_p
+    bogus = str(tmp_path / "nope.q3w").encode()
+    assert not lib.wrapper_load_model(bogus, 0)
+    assert not lib.cp_load(bogus, None, 1)
+    assert not lib.voc_load(bogus, 64, 1)
+    assert not lib.q3e_create(bogus, 1, 64, 8)
+    from qwen3_tts_axera_russian_amd.llama_cpp_bindings import LlamaCppModel
+    with pytest.raises(RuntimeError):
+        LlamaCppModel(str(tmp_path / "nope.q3w"))

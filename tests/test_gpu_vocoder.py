@@ -1,0 +1,95 @@
+"""Vocoder library (voc_* ABI) against an independent torch fp32 reference of the same op table,
+and its chunking/crossfade/int16 path against the restatement that is pinned to the reference's own
+VocoderServer.synthesize (tests/test_golden_frontend.py).  Waveform tolerance: exact-fp32 MFMA vs
+torch CPU differ only in summation order; 2e-4 of full scale is asserted (observed ~1e-6)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import frontend as fe
+from qwen3_tts_axera_russian_amd import hiplib
+from qwen3_tts_axera_russian_amd import weights as W
+from tests.util import CACHE
+from tests.voc_ref import voc_reference
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tiny_voc():
+    os.makedirs(CACHE, exist_ok=True)
+    path = os.path.join(CACHE, "voc_tiny_s7b.q3w")
+    vc = W.tiny_voc_config()
+    if not os.path.exists(path):
+        W.write_pack(path, {"voc_chunk": 64.0}, W.make_synthetic_voc(vc, seed=7))
+    _, tensors = W.read_pack(path)
+    return path, vc, tensors
+
+
+class Voc:
+    def __init__(self, lib, path, chunk=64, max_batch=4):
+        self.lib = lib
+        self.h = lib.voc_load(path.encode(), chunk, max_batch)
+        assert self.h
+        self.chunk, self.spt = lib.voc_chunk_tokens(self.h), lib.voc_samples_per_token(self.h)
+
+    def decode(self, codes):
+        codes = np.ascontiguousarray(codes, np.int64)
+        B = codes.shape[0]
+        out = np.empty((B, self.chunk * self.spt), np.float32)
+        assert self.lib.voc_decode(self.h, codes.ctypes.data_as(hiplib.i64p), B, hiplib.fptr(out)) == 0
+        return out
+
+    def synth_f32(self, codes):
+        codes = np.ascontiguousarray(codes, np.int64)
+        n = codes.shape[0]
+        out = np.empty(self.lib.voc_synthesize_max_samples(self.h, n), np.float32)
+        ns = np.zeros(1, np.int32)
+        assert self.lib.voc_synthesize_f32(self.h, codes.ctypes.data_as(hiplib.i64p), n, hiplib.fptr(out), hiplib.iptr(ns)) == 0
+        return out[:ns[0]]
+
+    def synth_i16(self, codes):
+        codes = np.ascontiguousarray(codes, np.int64)
+        n = codes.shape[0]
+        out = np.empty(self.lib.voc_synthesize_max_samples(self.h, n), np.int16)
+        ns = np.zeros(1, np.int32)
+        assert self.lib.voc_synthesize(self.h, codes.ctypes.data_as(hiplib.i64p), n, out.ctypes.data_as(hiplib.i16p), hiplib.iptr(ns)) == 0
+        return out[:ns[0]]
+
+    def close(self):
+        self.lib.voc_free(self.h)
+
+
+def test_decode_matches_torch_reference(gpu_lib, tiny_voc):
+    path, vc, tensors = tiny_voc
+    v = Voc(gpu_lib, path)
+    assert v.chunk == 64 and v.spt == 1920 == W.voc_total_upsample(vc)
+    rng = np.random.default_rng(3)
+    codes = rng.integers(0, 2048, size=(3, 64, 16)).astype(np.int64)
+    codes[2, 40:] = 0                      # the server's zero padding of a short chunk
+    codes[1, 5, 3] = 5000                  # out-of-range id embeds as zeros
+    got = v.decode(codes)
+    ref = voc_reference(tensors, codes)
+    assert got.shape == ref.shape == (3, 122880)
+    err = np.abs(got - ref).max()
+    print("vocoder max abs err:", err, "ref max:", np.abs(ref).max(), "clamped frac:", float((np.abs(ref) >= 1).mean()))
+    assert np.abs(ref).max() > 0.05        # a live signal, not silence
+    assert err < 2e-4
+    assert np.abs(got).max() <= 1.0        # final clamp
+    v.close()
+
+
+def test_synthesize_chunk_walk_and_int16(gpu_lib, tiny_voc):
+    path, vc, tensors = tiny_voc
+    v = Voc(gpu_lib, path, max_batch=1)
+    rng = np.random.default_rng(4)
+    for n in (1, 10, 64, 65, 97, 150):     # incl. the reference's length quirk (150 -> 156 frames)
+        codes = rng.integers(0, 2048, size=(n, 16)).astype(np.int64)
+        got = v.synth_f32(codes)
+        want = fe.voc_synthesize(codes, lambda padded: v.decode(padded)[0], 64)
+        assert len(got) == len(want), n
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(v.synth_i16(codes), fe.to_int16(want))
+    assert len(v.synth_f32(np.zeros((150, 16), np.int64))) == 156 * 1920
+    v.close()

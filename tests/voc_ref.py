@@ -1,0 +1,55 @@
+"""Independent fp32 reference of the vocoder program (torch CPU ops) -- test infrastructure.
+Follows the op-table semantics documented in DESIGN.md "Vocoder program"; the decoder's layer
+list itself is not in the reference: parity with the real model is unpinned."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from qwen3_tts_axera_russian_amd import weights as W
+
+
+def _snake(x, alpha, beta):
+    a = torch.exp(alpha)[None, :, None]
+    ib = 1.0 / (torch.exp(beta)[None, :, None] + 1e-9)
+    return x + ib * torch.sin(a * x) ** 2
+
+
+def voc_reference(tensors: dict, codes: np.ndarray, n_ops: int = -1) -> np.ndarray:
+    """codes int64 [B][T][16] -> wav f32 [B][T*upsample] (or the activation after n_ops ops)."""
+    prog = np.asarray(tensors["voc.program"])
+    t = lambda n: torch.from_numpy(np.array(tensors[n], dtype=np.float32))
+    codes_t = torch.from_numpy(np.asarray(codes, dtype=np.int64))
+    x, res = None, None
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        for i, row in enumerate(prog):
+            if 0 <= n_ops <= i:
+                break
+            op, p = int(row[0]), f"voc.op{i}."
+            if op == W.VOP_RVQ:
+                nq, cbs = int(row[1]), int(row[2])
+                cb = t(p + "codebook")
+                valid = ((codes_t >= 0) & (codes_t < cbs)).float()
+                idx = codes_t.clamp(0, cbs - 1)
+                emb = torch.stack([cb[q][idx[..., q]] * valid[..., q:q + 1] for q in range(nq)], 0)  # [nq,B,T,dim]
+                sem, ac = emb[0], emb[1:].sum(0)
+                y = sem @ t(p + "proj_sem").T + ac @ t(p + "proj_ac").T
+                x = y.transpose(1, 2).contiguous()
+            elif op in (W.VOP_CONV, W.VOP_CONVT):
+                k, p0, flags = int(row[3]), int(row[4]), int(row[5])
+                if flags & W.VF_RES_SAVE:
+                    res = x
+                h = _snake(x, t(p + "alpha"), t(p + "beta")) if flags & W.VF_SNAKE else x
+                bias = t(p + "bias") if (p + "bias") in tensors else None
+                if op == W.VOP_CONV:
+                    y = F.conv1d(F.pad(h, ((k - 1) * p0, 0)), t(p + "weight"), bias, dilation=p0)
+                else:
+                    y = F.conv_transpose1d(h, t(p + "weight"), bias, stride=p0)[..., : h.shape[-1] * p0]
+                if flags & W.VF_RES_ADD:
+                    y = y + res
+                if flags & W.VF_CLAMP:
+                    y = y.clamp(-1.0, 1.0)
+                x = y
+            else:
+                raise ValueError(f"unknown vocoder op {op}")
+    return x.numpy() if n_ops >= 0 else x[:, 0, :].numpy()
