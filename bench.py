@@ -5,8 +5,10 @@
 
 One "step" = one pass of the hot path over one batch of synthetic utterances: ragged prefill of B
 prompts + F autoregressive frames (talker step, 15-group code predictor, feedback) for all of them
-[+ the vocoder chunk of every utterance once the vocoder library is present], inputs (weights,
-prefix embeddings) resident in HBM/host-pinned before the timed region.  Utterances are independent:
++ the fp32 vocoder chunk (F=64 frames -> 5.12 s of 24 kHz audio) of every utterance; the vocoder of
+step i runs on its own stream while the frame loop of step i+1 proceeds (the streaming overlap of the
+reference client, tts_client.py:188-197).  Weights and prefix embeddings are resident before the
+timed region.  Utterances are independent:
 N GPUs = N replicas of the per-GPU batch, no collective on the data path (weak scaling); the only
 torch.distributed traffic is the barrier and the max-over-ranks of the elapsed time.
 
@@ -26,6 +28,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak (exact-fp32 MFMA)
 FRAME_SEC = 1920.0 / 24000.0      # one codec frame = 80 ms of audio (vocoder_server.py:29-30)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # token counts of the fixed mixed ru/en prompt set (5-40 tokens each; the first is the
@@ -42,6 +45,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (config 3/4: 32)")
     ap.add_argument("--frames", type=int, default=64, help="frames per utterance per step (one vocoder chunk)")
     ap.add_argument("--chains", type=int, default=0, help="parallel row groups per frame (0 = engine default)")
+    ap.add_argument("--no-vocoder", action="store_true", help="time the talker + code-predictor loop only")
     ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 latency leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-frames", type=int, default=12)
@@ -64,6 +68,15 @@ def make_pack(cache, seed, rank, barrier):
     return path, cfg
 
 
+def make_voc_pack(cache, seed, rank, barrier):
+    from qwen3_tts_axera_russian_amd import weights as W
+    path = os.path.join(cache, f"qwen3tts_voc_synth_s{seed}.q3w")
+    if rank == 0 and not os.path.exists(path):
+        W.write_pack(path, {"voc_chunk": 64.0}, W.make_synthetic_voc(W.VocConfig(), seed=seed))
+    barrier()
+    return path
+
+
 def workload(B, rank, seed):
     """B prompts of the fixed set (offset by rank): prefix rows = n_text + 9 (llamacpp_talker_server.py:121-161)."""
     rng = np.random.default_rng(seed + 1000 * rank)
@@ -73,24 +86,68 @@ def workload(B, rank, seed):
     return prefixes, n_text, pad
 
 
-def run_leg(eng, prefixes, n_text, pad, frames, steps, warmup, sync_all):
-    """-> (wall seconds for `steps` steps, mean GPU ms per frame step, mean prefill ms)."""
+class Vocoder:
+    """voc_* ABI wrapper; decode() is synchronous, so the bench runs it on a worker thread."""
+
+    def __init__(self, lib, path, max_batch, chunk=64):
+        from qwen3_tts_axera_russian_amd import hiplib
+        self.lib, self.hl = lib, hiplib
+        self.h = lib.voc_load(path.encode(), chunk, max_batch)
+        if not self.h:
+            raise SystemExit("bench.py: voc_load failed")
+        self.chunk, self.spt = lib.voc_chunk_tokens(self.h), lib.voc_samples_per_token(self.h)
+        self.out = np.empty((max_batch, self.chunk * self.spt), np.float32)
+        self.ms = []
+
+    def decode(self, codes_fb16):
+        """codes [F][B][16] int32 from the engine -> waveform [B][F*1920]."""
+        c = np.ascontiguousarray(np.transpose(codes_fb16, (1, 0, 2)).astype(np.int64))
+        B = c.shape[0]
+        rc = self.lib.voc_decode(self.h, c.ctypes.data_as(self.hl.i64p), B, self.hl.fptr(self.out))
+        assert rc == 0
+        self.ms.append(self.lib.voc_last_decode_ms(self.h))
+        return self.out[:B]
+
+    def close(self):
+        self.lib.voc_free(self.h)
+
+
+def run_leg(eng, voc, prefixes, n_text, pad, frames, steps, warmup, sync_all):
+    """-> (wall s for `steps` steps, mean GPU ms per frame step, mean prefill ms, mean vocoder ms)."""
+    from concurrent.futures import ThreadPoolExecutor
     eng.set_pad_embed(pad)
-    for _ in range(warmup):
-        eng.start(prefixes, n_text, ignore_eos=True, max_frames=frames)
-        eng.run(frames)
-    frame_ms, prefill_ms = [], []
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    pool = ThreadPoolExecutor(max_workers=1)
+
+    def one_step(pending):
         eng.start(prefixes, n_text, ignore_eos=True, max_frames=frames)
         ran = eng.run(frames)
         assert ran == frames
+        codes, _ = eng.codes()
+        if pending is not None:
+            pending.result()
+        return pool.submit(voc.decode, codes.copy()) if voc is not None else None
+
+    pending = None
+    for _ in range(warmup):
+        pending = one_step(pending)
+    if pending is not None:
+        pending.result()
+    if voc is not None:
+        voc.ms.clear()
+    frame_ms, prefill_ms = [], []
+    sync_all()
+    t0 = time.perf_counter()
+    pending = None
+    for _ in range(steps):
+        pending = one_step(pending)
         frame_ms.append(eng.last_run_ms / frames)
         prefill_ms.append(eng.last_prefill_ms)
+    if pending is not None:
+        pending.result()
     sync_all()
     dt = time.perf_counter() - t0
-    return dt, float(np.mean(frame_ms)), float(np.mean(prefill_ms))
+    pool.shutdown()
+    return dt, float(np.mean(frame_ms)), float(np.mean(prefill_ms)), float(np.mean(voc.ms)) if voc is not None else 0.0
 
 
 def kv_bytes_per_step(n_text, frames, cfg):
@@ -157,7 +214,12 @@ def main():
     eng = FrameEngine(path, max_batch=B, n_ctx=n_ctx, max_frames=F)
     if a.chains > 0:
         eng.set_chains(a.chains)
-    dt, frame_ms, prefill_ms = run_leg(eng, prefixes, n_text, pad, F, a.steps, a.warmup, sync_all)
+    voc = None
+    if not a.no_vocoder:
+        if F != 64:
+            raise SystemExit("bench.py: the vocoder leg decodes 64-frame chunks; use --frames 64 or --no-vocoder")
+        voc = Vocoder(lib, make_voc_pack(a.cache, a.seed, rank, barrier), B)
+    dt, frame_ms, prefill_ms, voc_ms = run_leg(eng, voc, prefixes, n_text, pad, F, a.steps, a.warmup, sync_all)
     step_w_bytes = eng.step_weight_bytes
     if dist is not None:
         import torch
@@ -180,20 +242,33 @@ def main():
                    "batch_per_gpu": B, "frames_per_step": F, "prompt_tokens": "5-40 (fixed set)"},
         "rtf": round((dt / a.steps) / (F * FRAME_SEC), 5),
         "rtf_aggregate": round((dt / a.steps) / (world * B * F * FRAME_SEC), 6),
-        "prefill_ms": round(prefill_ms, 3),
+        "prefill_ms": round(prefill_ms, 3), "vocoder_ms_per_step": round(voc_ms, 3),
         "roofline": {"kernel": "frame-step hipGraph (talker 28L + 16 CP passes + heads)", "bound": "hbm",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(frame_ms, 4)},
     }
+    if voc is not None:
+        fl = float(lib.voc_decode_flops(voc.h, B))
+        out["roofline_vocoder"] = {"kernel": "conv_kernel (fp32 MFMA implicit-GEMM conv stack, whole chunk)",
+                                   "bound": "mfma", "achieved": round(fl / (voc_ms * 1e-3) / 1e12, 2),
+                                   "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(fl / (voc_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                   "traffic": None, "flops_per_launch": fl, "avg_launch_ms": round(voc_ms, 3)}
+        voc.close()
     eng.destroy()
     if world == 1 and not a.no_b1:
         eng1 = FrameEngine(path, max_batch=1, n_ctx=n_ctx, max_frames=F)
-        dt1, frame_ms1, prefill_ms1 = run_leg(eng1, prefixes[:1], n_text[:1], pad, F, a.steps, a.warmup, sync_all)
+        voc1 = Vocoder(lib, make_voc_pack(a.cache, a.seed, rank, barrier), 1) if not a.no_vocoder else None
+        dt1, frame_ms1, prefill_ms1, voc_ms1 = run_leg(eng1, voc1, prefixes[:1], n_text[:1], pad, F, a.steps, a.warmup,
+                                                       sync_all)
+        if voc1 is not None:
+            voc1.close()
         ab1 = step_w_bytes + kv_bytes_per_step(n_text[:1], F, cfg)
         out["batch1"] = {"workload": "configs[1]: batch=1, same engine", "value": round(F * a.steps / dt1, 1),
                          "unit": "codec_frames/s", "rtf": round((dt1 / a.steps) / (F * FRAME_SEC), 5),
                          "ms_per_frame": round(frame_ms1, 4), "prefill_ms": round(prefill_ms1, 3),
+                         "vocoder_ms_per_chunk": round(voc_ms1, 3),
                          "hbm_frac": round(ab1 / (frame_ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         eng1.destroy()
     if rank == 0 and world == 1 and not a.no_cpu:

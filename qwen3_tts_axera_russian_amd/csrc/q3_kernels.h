@@ -17,6 +17,7 @@ struct LinArgs {
     const half_t* wp = nullptr;  // packed weights
     int N = 0, K = 0, M = 0;   // rows [m_begin, M) are computed
     int m_begin = 0;
+    int swap_grid = 0;  // set by the launcher
     int nt = 0;  // 1: stream the weights with non-temporal loads (read once per step: talker)
     // prologue PRO_F16: A = x16[M][K] (fp16).  PRO_NORM: A = fp16((h*inv)*gamma),
     // inv[m] = 1/sqrt(sum(ssq[m][0..ssq_parts))/K + eps).

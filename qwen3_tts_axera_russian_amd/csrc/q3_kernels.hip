@@ -115,8 +115,10 @@ __global__ void __launch_bounds__(NW * 64) linear_kernel(LinArgs a) {
     Q3_TL(10 + PRO * 4 + EPI);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int q = lane >> 4, c = lane & 15;
-    const int tile0 = blockIdx.x * NB16;
-    const int m0 = a.m_begin + blockIdx.y * MR;
+    // many row blocks (prefill): the row block is the fast grid index, so the blocks that share a
+    // weight tile run back to back and the tile is streamed from HBM once
+    const int tile0 = (a.swap_grid ? blockIdx.y : blockIdx.x) * NB16;
+    const int m0 = a.m_begin + (a.swap_grid ? blockIdx.x : blockIdx.y) * MR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)smem;             // [NW][MR][NBP]
     float* inv_s = red + NW * MR * NBP;    // [MR]
@@ -287,7 +289,7 @@ __global__ void __launch_bounds__(NW * 64) linear_kernel(LinArgs a) {
                 const int m = m0 + mr;
                 if (m < a.M) {
                     const float sg = g / (1.0f + expf(-g));
-                    a.act[(size_t)m * (a.N / 2) + (size_t)blockIdx.x * NH + j] = sat_half(sg * u);
+                    a.act[(size_t)m * (a.N / 2) + (size_t)(tile0 / NB16) * NH + j] = sat_half(sg * u);
                 }
             }
         }
@@ -305,8 +307,11 @@ static int launch_linear_nt(hipStream_t s, const LinArgs& a) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), -1);
         attr_set = true;
     }
-    dim3 grid(a.N / (16 * NB16), (a.M - a.m_begin + MR - 1) / MR);
-    hipLaunchKernelGGL((linear_kernel<NB16, MT16, KBW, NW, PRO, EPI, NT>), grid, dim3(NW * 64), lds, s, a);
+    LinArgs b = a;
+    const unsigned nt_ = a.N / (16 * NB16), nr_ = (a.M - a.m_begin + MR - 1) / MR;
+    b.swap_grid = nr_ > 2 ? 1 : 0;
+    dim3 grid(b.swap_grid ? nr_ : nt_, b.swap_grid ? nt_ : nr_);
+    hipLaunchKernelGGL((linear_kernel<NB16, MT16, KBW, NW, PRO, EPI, NT>), grid, dim3(NW * 64), lds, s, b);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
 }
