@@ -28,7 +28,8 @@ void q3e_free(void* e);
 
 /* Split every frame step into n (1..8) independent row groups that run as parallel branches of the
  * captured graph: hides per-kernel launch latency behind the other groups' work at the price of
- * streaming the weights n times.  Default: 2 when max_batch >= 16, else 1 (env Q3_CHAINS overrides). */
+ * streaming the weights n times.  Default 1 (env Q3_CHAINS overrides): on ROCm 7.2 the
+ * per-chain graphs were measured NOT to overlap, so more chains only re-stream the weights. */
 int q3e_set_chains(void* e, int n);
 
 /* tts_pad embedding added to every feedback (tts_client.py:207-208); zeros until set. */

@@ -864,20 +864,38 @@ __device__ __forceinline__ void feedback_row(const int* codes, int r, const floa
     }
 }
 
-// One wave per row: no barriers; the logits come in as float4s, the winner leaves by shuffles.
-__global__ void __launch_bounds__(64) cp_argmax_kernel(CpArgmaxArgs a) {
+// One workgroup per row: the 2048 logits arrive as two float4 per thread (one round trip), one barrier
+// picks the winner, then the next embedding row is gathered (second round trip).
+__global__ void __launch_bounds__(256) cp_argmax_kernel(CpArgmaxArgs a) {
     Q3_TL(43);
-    const int r = a.row0 + blockIdx.x, lane = threadIdx.x;
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int r = a.row0 + blockIdx.x, tid = threadIdx.x;
     const int RT = a.R_total > 0 ? a.R_total : a.R;
     float best = -INFINITY;
     int bidx = 0x7fffffff;
     const float4* lg = (const float4*)(a.logits + (size_t)r * a.V);
-    for (int v4 = lane; v4 < a.V / 4; v4 += 64) {
+    const int n4 = a.V / 4;
+    float4 l0 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), l1 = l0;
+    if (tid < n4) l0 = lg[tid];
+    if (tid + 256 < n4) l1 = lg[tid + 256];
+    {
+        const float e[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int idx = (j < 4 ? tid : tid + 256) * 4 + (j & 3);
+            if (e[j] > best) {   // ascending index within a thread: strict > keeps the lowest index
+                best = e[j];
+                bidx = idx;
+            }
+        }
+    }
+    for (int v4 = tid + 512; v4 < n4; v4 += 256) {   // vocabularies beyond 2048
         const float4 l = lg[v4];
         const float e[4] = {l.x, l.y, l.z, l.w};
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            if (e[j] > best) {   // ascending index within a lane: strict > keeps the lowest index
+            if (e[j] > best) {
                 best = e[j];
                 bidx = v4 * 4 + j;
             }
@@ -891,16 +909,29 @@ __global__ void __launch_bounds__(64) cp_argmax_kernel(CpArgmaxArgs a) {
             bidx = oi;
         }
     }
+    if ((tid & 63) == 0) {
+        sv[tid >> 6] = best;
+        si[tid >> 6] = bidx;
+    }
+    __syncthreads();
+    best = sv[0];
+    bidx = si[0];
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+        if (sv[i] > best || (sv[i] == best && si[i] < bidx)) {
+            best = sv[i];
+            bidx = si[i];
+        }
     int f = a.n_frames[r] - 1;
     if (f < 0) f = 0;
     if (f >= a.frame_cap) f = a.frame_cap - 1;
     int* fc = a.codes + ((size_t)f * RT + r) * 16;
-    if (lane == 0) fc[1 + a.group] = bidx;
+    if (tid == 0) fc[1 + a.group] = bidx;
     if (a.talker_emb) {
         feedback_row(fc, r, a.talker_emb, a.talker_vocab, a.cp_tables, a.V, a.n_groups, a.pad_embed,
                      a.h_out, a.ssq_out, a.H, a.group, bidx);
     } else if (a.next_table) {
-        for (int k4 = lane; k4 < a.H / 4; k4 += 64) {
+        for (int k4 = tid; k4 < a.H / 4; k4 += 256) {
             const float4 v = *(const float4*)(a.next_table + (size_t)bidx * a.H + k4 * 4);
             store_row_ssq(a.h_out, a.ssq_out, r, a.H, k4, v);
         }
@@ -908,7 +939,7 @@ __global__ void __launch_bounds__(64) cp_argmax_kernel(CpArgmaxArgs a) {
 }
 int launch_cp_argmax(hipStream_t s, const CpArgmaxArgs& a) {
     if (a.R <= 0) return 0;
-    hipLaunchKernelGGL(cp_argmax_kernel, dim3(a.R), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(cp_argmax_kernel, dim3(a.R), dim3(256), 0, s, a);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
 }

@@ -268,7 +268,26 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
     Voc* v = new Voc();
     v->chunk = chunk_tokens > 0 ? chunk_tokens : 64;
     v->max_batch = max_batch > 0 ? max_batch : 1;
-    bool ok = hipStreamCreateWithFlags(&v->s, hipStreamNonBlocking) == hipSuccess;
+    // Q3_VOC_CUS=n: confine the vocoder's stream to n compute units, spread evenly over the XCDs (bit i of
+    // the mask = CU i), so a concurrently running latency-bound frame loop keeps the others to itself.
+    bool ok = true;
+    int n_cus = getenv("Q3_VOC_CUS") ? atoi(getenv("Q3_VOC_CUS")) : 0;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (n_cus > 0 && hipGetDeviceProperties(&prop, dev) == hipSuccess && n_cus < prop.multiProcessorCount) {
+        const int total = prop.multiProcessorCount;
+        std::vector<uint32_t> mask((total + 31) / 32, 0u);
+        // take every k-th CU so that each XCD / shader engine contributes equally
+        for (int i = 0; i < n_cus; i++) {
+            const int cu = (int)((long long)i * total / n_cus);
+            mask[cu / 32] |= 1u << (cu % 32);
+        }
+        ok = hipExtStreamCreateWithCUMask(&v->s, (uint32_t)mask.size(), mask.data()) == hipSuccess;
+        if (!ok) Q3_LOG("hipExtStreamCreateWithCUMask failed");
+    } else {
+        ok = hipStreamCreateWithFlags(&v->s, hipStreamNonBlocking) == hipSuccess;
+    }
     ok = ok && hipEventCreate(&v->e0) == hipSuccess && hipEventCreate(&v->e1) == hipSuccess;
     const int32_t* pr = (const int32_t*)prog->data;
     const int n_ops = (int)prog->shape[0];
