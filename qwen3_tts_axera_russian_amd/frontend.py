@@ -1,0 +1,96 @@
+"""Host-side front-end arithmetic of the talker server: text projection, dual-stream prefix, sampling.
+
+Mirrors (same argument meaning and results) Qwen3TTSTalkerServer._embed_text / _build_prefix /
+_sample_token of the reference (dual_npu/llamacpp_talker_server.py:115-206).  Runs once per utterance /
+once per frame on small vectors; the GEMMs behind it (talker, codec head) are on the GPU.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class TextFrontEnd:
+    """text ids -> prefix embedding rows [n_text + 9, hidden] (llamacpp_talker_server.py:115-161)."""
+
+    def __init__(self, cfg, text_embedding, fc1_w, fc1_b, fc2_w, fc2_b, codec_embedding):
+        self.cfg = cfg
+        self.table = text_embedding
+        self.fc1_w, self.fc1_b, self.fc2_w, self.fc2_b = fc1_w, fc1_b, fc2_w, fc2_b
+        self.codec = codec_embedding
+        sp = self.embed_text([cfg.tts_pad, cfg.tts_bos, cfg.tts_eos])
+        self.tts_pad_embed, self.tts_bos_embed, self.tts_eos_embed = sp[0], sp[1], sp[2]
+
+    def embed_text(self, token_ids):
+        rows = self.table[np.asarray(token_ids, dtype=np.int64)].astype(np.float32, copy=False)
+        h = rows @ self.fc1_w.T + self.fc1_b
+        h = h * (1.0 / (1.0 + np.exp(-h)))          # SiLU
+        return (h @ self.fc2_w.T + self.fc2_b).astype(np.float32)
+
+    def build_prefix(self, text_token_ids, language="russian"):
+        """Text stream + codec stream, summed per position.  `language` is accepted and unused, as in
+        the reference (parsed, passed, never read)."""
+        c, cod = self.cfg, self.codec
+        n = len(text_token_ids)
+        out = np.empty((n + 9, cod.shape[1]), np.float32)
+        out[0:3] = self.embed_text([c.im_start, c.assistant, c.newline])            # role rows: text only
+        out[3:6] = self.tts_pad_embed + cod[[c.codec_nothink, c.codec_think_bos, c.codec_think_eos]]
+        out[6] = self.tts_bos_embed + cod[c.codec_pad]
+        if n:
+            out[7:7 + n] = self.embed_text(text_token_ids) + cod[c.codec_pad]
+        out[7 + n] = self.tts_eos_embed + cod[c.codec_pad]
+        out[8 + n] = self.tts_pad_embed + cod[c.codec_bos]
+        return out
+
+
+class TalkerSampler:
+    """Codec-token sampling with the reference's heuristics (llamacpp_talker_server.py:163-206): mask of
+    ids 2048..2149 and >= 2151, adaptive EOS boost, repetition penalty over the set of the last 30
+    tokens, top-k / temperature / top-p 0.95.  temperature <= 1e-6 = arg-max (the reference's limit)."""
+
+    def __init__(self, eos=2150, audio_vocab=2048, temperature=0.8, top_k=50, top_p=0.95, rng=None):
+        self.eos, self.audio_vocab = eos, audio_vocab
+        self.temperature, self.top_k, self.top_p = temperature, top_k, top_p
+        self.rng = rng if rng is not None else np.random
+
+    def process(self, logits, past_tokens, n_text_tokens):
+        l = np.array(logits, dtype=np.float32, copy=True)
+        l[self.audio_vocab:self.eos] = -1e10
+        l[self.eos + 1:] = -1e10
+        forced = None
+        if past_tokens is not None and n_text_tokens > 0:
+            progress = len(past_tokens) / (n_text_tokens * 3)
+            if progress > 0.8:
+                l[self.eos] += min((progress - 0.8) / 0.7, 1.0) * 15.0
+            if progress > 2.0:
+                forced = self.eos
+        if past_tokens:
+            for t in set(past_tokens[-30:]):
+                if 0 <= t < len(l):
+                    l[t] = l[t] / 1.2 if l[t] > 0 else l[t] * 1.2
+        return l, forced
+
+    def sample(self, logits, past_tokens=None, n_text_tokens=0):
+        l, forced = self.process(logits, past_tokens, n_text_tokens)
+        if forced is not None:
+            return int(forced)
+        if self.temperature <= 1e-6:
+            return int(np.argmax(l))
+        top = np.argsort(l)[-self.top_k:]
+        z = l[top] / max(self.temperature, 1e-6)
+        p = np.exp(z - z.max())
+        p /= p.sum()
+        order = np.argsort(-p)
+        keep = order[:np.searchsorted(np.cumsum(p[order]), self.top_p) + 1]
+        pk = p[keep] / p[keep].sum()
+        return int(top[keep[self.rng.choice(len(keep), p=pk)]])
+
+
+def feedback_embedding(code_0, codes_1_15, codec_embedding, cp_codec_embeddings, tts_pad_embed):
+    """Next talker input (tts_client.py:199-208): talker table row of code_0, plus CP table g row of
+    code g+1 for g = 0..14 in that order, plus the tts_pad embedding."""
+    buf = codec_embedding[code_0].astype(np.float32, copy=True)
+    for g, tok in enumerate(codes_1_15):
+        buf += cp_codec_embeddings[g][tok]
+    if tts_pad_embed is not None:
+        buf += tts_pad_embed
+    return buf

@@ -1,0 +1,84 @@
+"""End-to-end over the reference's socket protocol: the three servers (talker, code predictor,
+vocoder) in threads, the client driving them; the codec ids must equal the fused engine's (same
+greedy decode, same kernels) and the WAV must equal the vocoder library's output for those ids."""
+import os
+import threading
+import time
+import wave
+
+import numpy as np
+import pytest
+
+from qwen3_tts_axera_russian_amd import weights as W
+from tests.util import CACHE
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def packs():
+    os.makedirs(CACHE, exist_ok=True)
+    cfg = W.tiny_config(2, 2, text_vocab=512)
+    cfg.text_dim = 64
+    main = os.path.join(CACHE, "srv_tiny_t2c2.q3w")
+    if not os.path.exists(main):
+        W.write_synthetic(main, cfg, seed=1234, parts=("talker", "cp", "text"))
+    voc = os.path.join(CACHE, "srv_voc_tiny.q3w")
+    if not os.path.exists(voc):
+        W.write_pack(voc, {"voc_chunk": 64.0}, W.make_synthetic_voc(W.tiny_voc_config(), seed=7))
+    return main, voc, cfg
+
+
+def _wait(path):
+    for _ in range(200):
+        if os.path.exists(path):
+            return
+        time.sleep(0.05)
+    raise RuntimeError(f"{path} did not appear")
+
+
+def test_three_servers_and_client(gpu_lib, packs, tmp_path):
+    from qwen3_tts_axera_russian_amd.code_predictor_server import CodePredictorServer
+    from qwen3_tts_axera_russian_amd.engine import FrameEngine
+    from qwen3_tts_axera_russian_amd.llamacpp_talker_server import Qwen3TTSTalkerServer
+    from qwen3_tts_axera_russian_amd.tts_client import Qwen3TTSClient
+    from qwen3_tts_axera_russian_amd.vocoder_server import VocoderServer
+    main, voc, cfg = packs
+    socks = {k: str(tmp_path / f"{k}.sock") for k in ("talker", "cp", "voc")}
+    talker = Qwen3TTSTalkerServer(main, socket_path=socks["talker"], temperature=0.0, max_tokens=70,
+                                  kv_cache_dir=str(tmp_path), n_ctx=128, install_signal_handlers=False)
+    cp = CodePredictorServer(main, socket_path=socks["cp"], temperature=0.0, install_signal_handlers=False)
+    vs = VocoderServer(voc, socks["voc"], install_signal_handlers=False)
+    threads = [threading.Thread(target=s.serve, daemon=True) for s in (talker, cp, vs)]
+    for t in threads:
+        t.start()
+    for p in socks.values():
+        _wait(p)
+    ids = [5, 17, 200, 33, 41, 7, 90, 120, 64, 3, 11, 250, 77, 8, 19, 300, 45, 60, 2, 150, 99, 21, 13, 55, 180]
+    client = Qwen3TTSClient(socks["talker"], socks["cp"], socks["voc"], weights=main)
+    wav = str(tmp_path / "out.wav")
+    codes, audio = client.synthesize("ignored", "russian", wav, streaming=False, token_ids=ids)
+    n = codes.shape[0]
+    assert 1 <= n <= 70 and codes.shape[1] == 16 and (codes >= 0).all() and (codes < 2048).all()
+    with wave.open(wav) as wf:
+        assert (wf.getnchannels(), wf.getsampwidth(), wf.getframerate()) == (1, 2, 24000)
+        assert wf.getnframes() == len(audio)
+    # same ids from the fused on-device loop (identical kernels, greedy)
+    prefix = talker._build_prefix(ids)
+    eng = FrameEngine(main, max_batch=1, n_ctx=128, max_frames=80)
+    eng.set_pad_embed(talker.tts_pad_embed)
+    eng.start([prefix], [len(ids)], ignore_eos=False, max_frames=70)
+    eng.run(70)
+    ecodes, per = eng.codes()
+    assert int(per[0]) == n
+    np.testing.assert_array_equal(ecodes[:n, 0, :], codes)
+    eng.destroy()
+    # audio = the vocoder server's synthesize of those ids (multi-chunk path when n > 64)
+    np.testing.assert_array_equal(audio, vs.synthesize_int16(codes.astype(np.int64)))
+    # second request hits the KV prefix cache (llamacpp_talker_server.py:226-236) and reproduces the ids
+    codes2, _ = client.synthesize("ignored", "russian", wav, streaming=True, token_ids=ids)
+    np.testing.assert_array_equal(codes2, codes)
+    for s in (talker, cp, vs):
+        s._running = False
+    for t in threads:
+        t.join(timeout=5)

@@ -1,0 +1,63 @@
+"""The product's host-side front-end (frontend.py, protocol.py) against vectors produced by the
+reference's own Python (tests/golden).  CPU only."""
+import json
+import struct
+
+import numpy as np
+import pytest
+
+from qwen3_tts_axera_russian_amd import frontend as fe
+from qwen3_tts_axera_russian_amd import protocol as P
+from qwen3_tts_axera_russian_amd.weights import ModelConfig
+from tests.test_golden_frontend import _talker_tables
+
+
+@pytest.fixture(scope="module")
+def tt(golden):
+    H, TD, TV, CV = (int(x) for x in golden["talker_dims"])
+    return _talker_tables(int(golden["talker_seed"]), H, TD, TV, CV)
+
+
+def test_prefix_matches_reference(golden, tt):
+    front = fe.TextFrontEnd(ModelConfig(), tt["text_embedding"], tt["fc1_w"], tt["fc1_b"], tt["fc2_w"], tt["fc2_b"],
+                            tt["codec_embedding"])
+    for i in range(3):
+        ids = [int(x) for x in golden[f"prefix_{i}_ids"]]
+        np.testing.assert_array_equal(front.build_prefix(ids), golden[f"prefix_{i}_out"])
+    assert front.build_prefix([]).shape == (9, tt["codec_embedding"].shape[1])   # empty text: 9 rows
+
+
+def test_sampler_matches_reference(golden, tt):
+    s = fe.TalkerSampler(temperature=0.0)
+    for ci in range(int(golden["sample_n"])):
+        past = [int(x) for x in golden[f"sample_{ci}_past"]]
+        past_arg = past if ci % 5 else (past or None)
+        logits = golden[f"sample_{ci}_hidden"] @ tt["codec_head"].T
+        assert s.sample(logits, past_arg, int(golden[f"sample_{ci}_ntext"])) == int(golden[f"sample_{ci}_tok"]), ci
+    np.random.seed(1234)
+    st = fe.TalkerSampler(temperature=0.8, top_k=50, rng=np.random)
+    toks = [st.sample(golden[f"sample_{ci}_hidden"] @ tt["codec_head"].T, [int(x) for x in golden[f"sample_{ci}_past"]],
+                      int(golden[f"sample_{ci}_ntext"])) for ci in range(8)]
+    np.testing.assert_array_equal(np.array(toks), golden["sample_stoch_toks"])
+
+
+def test_feedback_matches_reference(golden):
+    tr = np.random.default_rng(int(golden["client_seed"]))
+    codec = (0.5 * tr.standard_normal((3072, 1024))).astype(np.float32)
+    cp_emb = [(0.5 * tr.standard_normal((2048, 1024))).astype(np.float32) for _ in range(15)]
+    pad = (0.5 * tr.standard_normal(1024)).astype(np.float32)
+    for f in range(3):
+        got = fe.feedback_embedding(int(golden["client_code0"][f]), [int(x) for x in golden["client_cp"][f]], codec, cp_emb, pad)
+        np.testing.assert_array_equal(got, golden["client_feedback"][f])
+
+
+def test_wire_messages_are_byte_identical_to_the_reference_client(golden):
+    assert P.pack_talker_request("Привет", "russian") == golden["client_talker_request"].tobytes()
+    assert P.pack_cp_request(golden["client_hidden"][0], int(golden["client_code0"][0])) == golden["client_cp_request_0"].tobytes()
+    codes = np.concatenate([golden["client_code0"][:, None], golden["client_cp"]], axis=1)
+    assert P.pack_voc_request(codes) == golden["client_voc_request"].tobytes()
+    assert P.pack_cp_reply(range(15)) == struct.pack("<15i", *range(15))
+    assert len(P.pack_talker_frame(7, np.zeros(1024, np.float32))) == 4100
+    assert P.pack_sentinel(P.SENTINEL_DONE) == struct.pack("<i", -1)
+    msg = json.loads(P.pack_talker_request("x", "english", [1, 2])[4:].decode())
+    assert msg["token_ids"] == [1, 2]
