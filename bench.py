@@ -177,21 +177,60 @@ def cpu_baseline(path, cfg, prefix, n_text, pad, frames):
                       f"fp32 C/OpenMP restatement of the same fp16-weight contract), {dt:.1f}s"}
 
 
+class Ranks:
+    """One process per GPU.  The data path has no collective (utterances are independent); the process
+    group only carries the barrier and the max-over-ranks of the elapsed time.  backend "nccl" is RCCL
+    on ROCm; "gloo" is used by the CPU tests of this logic."""
+
+    def __init__(self, backend="nccl"):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend, self.dist = backend, None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            if backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(backend=backend)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def sync_all(self):
+        if self.dist is not None:
+            if self.backend == "nccl":
+                import torch
+                torch.cuda.synchronize()
+            self.dist.barrier()
+
+    def max_over_ranks(self, x: float) -> float:
+        if self.dist is None:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def aggregate_value(world, B, frames, steps, dt_max):
+    """Whole-job codec frames/s: every rank processed B*frames*steps frames in dt_max seconds."""
+    return world * B * frames * steps / dt_max
+
+
 def main():
     a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    R = Ranks("nccl")
+    rank, world, local_rank, dist = R.rank, R.world, R.local_rank, R.dist
+    barrier = R.barrier
 
     from qwen3_tts_axera_russian_amd import hiplib
     from qwen3_tts_axera_russian_amd.engine import FrameEngine
@@ -200,12 +239,7 @@ def main():
         raise SystemExit("bench.py: no HIP device -- the HIP library is the only compute path")
     lib.q3_set_device(local_rank % lib.q3t_device_count())
 
-    def sync_all():
-        # engine calls are synchronous (each q3e_run ends with a stream sync); ranks meet at the barrier
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
+    sync_all = R.sync_all  # engine calls are synchronous (every q3e_run ends with a stream sync)
 
     path, cfg = make_pack(a.cache, a.seed, rank, barrier)
     B, F = a.batch, a.frames
@@ -221,13 +255,8 @@ def main():
         voc = Vocoder(lib, make_voc_pack(a.cache, a.seed, rank, barrier), B)
     dt, frame_ms, prefill_ms, voc_ms = run_leg(eng, voc, prefixes, n_text, pad, F, a.steps, a.warmup, sync_all)
     step_w_bytes = eng.step_weight_bytes
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    total_frames = world * B * F * a.steps
-    value = total_frames / dt
+    dt = R.max_over_ranks(dt)
+    value = aggregate_value(world, B, F, a.steps, dt)
     ms_per_step = dt / a.steps * 1e3
     algo_bytes = step_w_bytes + kv_bytes_per_step(n_text, F, cfg)
     achieved = algo_bytes / (frame_ms * 1e-3) / 1e9
@@ -275,8 +304,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(path, cfg, prefixes[0], n_text[0], pad, a.cpu_frames)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    R.close()
 
 
 if __name__ == "__main__":
