@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (config 3/4: 32)")
     ap.add_argument("--frames", type=int, default=64, help="frames per utterance per step (one vocoder chunk)")
     ap.add_argument("--chains", type=int, default=0, help="parallel row groups per frame (0 = engine default)")
+    ap.add_argument("--voc-wgs", type=int, default=-1, help="cap of workgroups per vocoder launch (-1 = default)")
     ap.add_argument("--no-vocoder", action="store_true", help="time the talker + code-predictor loop only")
     ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 latency leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -252,6 +253,8 @@ def main():
     if not a.no_vocoder:
         if F != 64:
             raise SystemExit("bench.py: the vocoder leg decodes 64-frame chunks; use --frames 64 or --no-vocoder")
+        if a.voc_wgs >= 0:
+            lib.voc_set_max_workgroups(a.voc_wgs)
         voc = Vocoder(lib, make_voc_pack(a.cache, a.seed, rank, barrier), B)
     dt, frame_ms, prefill_ms, voc_ms = run_leg(eng, voc, prefixes, n_text, pad, F, a.steps, a.warmup, sync_all)
     step_w_bytes = eng.step_weight_bytes

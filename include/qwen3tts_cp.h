@@ -14,7 +14,9 @@
  * TALKER codec table (code_predictor_server.py:97-98); group g>=1 embeds the
  * previous token with CP table g-1 (:134); positions 0..15; an out-of-range
  * token embeds as zeros (code_predictor_server.cpp:374-380).  temperature <=
- * 1e-6 is greedy (the reference's max(T,1e-6) softmax collapses to argmax).
+ * 1e-6 is greedy (the reference's max(T,1e-6) softmax collapses to argmax); above it the device
+ * draws from the top_k (<= 64) logits with softmax((l-max)/T) using a counter-based generator keyed by
+ * `seed` (reproducible per seed; not numpy's / mt19937's stream).
  *
  * Buffers are caller-owned host memory; calls are synchronous; one caller
  * thread per handle.  No CPU fallback.

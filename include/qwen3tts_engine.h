@@ -26,6 +26,14 @@ extern "C" {
 void* q3e_create(const char* weights, int max_batch, int n_ctx, int max_frames);
 void q3e_free(void* e);
 
+/* Sampling.  Defaults are greedy (temperature 0 = the reference's --temperature 0 limit).  With
+ * temperature > 1e-6 the device draws from top-k / temperature (/ top-p for the talker) like
+ * llamacpp_talker_server.py:191-206 and code_predictor_server.py:87-92; the generator is counter based
+ * (seed, utterance, frame, group), so a run is reproducible for a seed but not bit-compatible with
+ * numpy's or mt19937's streams. */
+int q3e_set_sampling(void* e, float talker_temperature, int talker_top_k, float talker_top_p,
+                     float cp_temperature, int cp_top_k, uint64_t seed);
+
 /* Split every frame step into n (1..8) independent row groups that run as parallel branches of the
  * captured graph: hides per-kernel launch latency behind the other groups' work at the price of
  * streaming the weights n times.  Default 1 (env Q3_CHAINS overrides): on ROCm 7.2 the

@@ -44,6 +44,11 @@ int voc_synthesize(void* v, const int64_t* codes, int n_tokens, int16_t* out, in
 int voc_synthesize_f32(void* v, const int64_t* codes, int n_tokens, float* out, int32_t* n_samples);
 int voc_synthesize_max_samples(void* v, int n_tokens);
 
+/* Cap the workgroups each vocoder kernel launch occupies (0 = one per output tile).  With a cap the
+ * kernels walk their tiles persistently and leave the other compute units to a concurrently running
+ * frame loop (talker / code predictor), which is latency-bound and would otherwise starve. */
+int voc_set_max_workgroups(int n);
+
 /* GPU milliseconds of the last voc_decode (HIP events on the library's stream) and its FLOP count. */
 float voc_last_decode_ms(void* v);
 double voc_decode_flops(void* v, int B);

@@ -19,7 +19,7 @@ from .llama_cpp_bindings import CodePredictor
 
 
 class CodePredictorServer:
-    def __init__(self, model_dir, embeddings_dir=None, socket_path="/tmp/qwen3_cp.sock", temperature=0.0, top_k=50,
+    def __init__(self, model_dir, embeddings_dir=None, socket_path="/tmp/qwen3_cp.sock", temperature=0.1, top_k=50,
                  n_threads=1, batch_prefill=False, install_signal_handlers=True):
         self.socket_path, self.temperature, self.top_k = socket_path, temperature, top_k
         self.num_groups = P.NUM_CP_CODES
@@ -78,8 +78,7 @@ def main():
     ap.add_argument("--model_dir", "--model", dest="model", required=True, help="Q3TTSW1 container (cp.*, talker.codec_embedding)")
     ap.add_argument("--embeddings_dir", default=None)
     ap.add_argument("--socket", default="/tmp/qwen3_cp.sock")
-    ap.add_argument("--temperature", type=float, default=0.0,
-                    help="only greedy (<=1e-6) is built on the device in this round; the reference defaults to 0.1")
+    ap.add_argument("--temperature", type=float, default=0.1)
     ap.add_argument("--top_k", type=int, default=50)
     ap.add_argument("--threads", type=int, default=3)
     ap.add_argument("--batch_prefill", action="store_true", help="accepted; positions 0/1 always run exactly")

@@ -12,6 +12,10 @@ struct CpFrameIO {
     float* fb_h = nullptr;
     float* fb_ssq = nullptr;
     const float* pad_embed = nullptr;
+    // sampling of the 15 groups (code_predictor_server.py:87-92): temperature <= 1e-6 = arg-max
+    float temperature = 0.f;
+    int top_k = 50;
+    unsigned long long seed = 0;
 };
 
 // w.h / w.ssq hold the talker hidden of each row (position 0 input).  Runs positions 0..n_groups,

@@ -51,6 +51,9 @@ int cp_frame(hipStream_t s, const Model& m, Work& w, KVCache& kv, int R, const C
         x.codes = io.codes;
         x.n_frames = io.n_frames;
         x.frame_cap = io.frame_cap;
+        x.temperature = io.temperature;
+        x.top_k = io.top_k;
+        x.seed = io.seed;
         if (g + 1 < G) {
             x.next_table = m.cp_emb[g];  // group g+1 embeds token g with CP table g (:134)
             x.h_out = w.h;
@@ -156,13 +159,8 @@ int cp_hidden_size(void* hh) {
 int cp_predict_batch(void* hh, const float* hidden, const int32_t* code_0, int n_rows, float temperature, int top_k,
                      uint64_t seed, int32_t* out_codes) {
     CpHandle* h = (CpHandle*)hh;
-    (void)top_k;
-    (void)seed;
     if (!h || !hidden || !code_0 || !out_codes || n_rows <= 0 || n_rows > h->max_batch) return -1;
-    if (temperature > 1e-6f) {
-        Q3_LOG("cp_predict: stochastic sampling (temperature %g) is not built yet; greedy only", temperature);
-        return -3;
-    }
+    const bool stochastic = temperature > 1e-6f;
     const Model& m = *h->m;
     const int H = m.cfg.hidden, G = m.cfg.cp_groups, R = n_rows;
     for (int r = 0; r < R; r++) {
@@ -175,11 +173,17 @@ int cp_predict_batch(void* hh, const float* hidden, const int32_t* code_0, int n
     io.codes = h->d_codes;
     io.n_frames = h->d_nframes;
     io.frame_cap = 1;
+    io.temperature = temperature;
+    io.top_k = top_k;
+    io.seed = seed;
     auto body = [&]() -> int {
         if (launch_ssq_rows(h->s, h->w.h, h->w.ssq, R, H)) return -1;
         return cp_frame(h->s, m, h->w, h->kv, R, io);
     };
-    if (!h->graph.e || h->graph_rows != R) {
+    if (stochastic) {
+        // sampling parameters and seed change per call: launch eagerly (the greedy path keeps its graph)
+        if (body()) return -1;
+    } else if (!h->graph.e || h->graph_rows != R) {
         if (body()) return -1;  // eager once (kernel attributes), result is valid
         Q3_HIP(hipStreamSynchronize(h->s), -1);
         h->graph.reset();

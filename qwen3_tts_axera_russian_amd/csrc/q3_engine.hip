@@ -34,6 +34,10 @@ struct Engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_run_ms = 0.f, last_prefill_ms = 0.f, last_host_launch_ms = 0.f;
     int* h_done = nullptr;  // pinned [max_batch]
+    // sampling (0 temperature = greedy, the reference's --temperature 0 limit)
+    float t_temp = 0.f, t_top_p = 0.95f, c_temp = 0.f;
+    int t_top_k = 50, c_top_k = 50;
+    unsigned long long seed = 0;
     // independent row groups of one frame run as parallel branches of the graph (latency hiding)
     int n_chains = 1;
     hipStream_t cs[8] = {nullptr};
@@ -92,6 +96,10 @@ int frame_chain(Engine* e, hipStream_t st, int row0, int R) {
     sa.pos = e->d_posdec;
     sa.ignore_eos = e->ignore_eos;
     sa.max_frames = e->cap_frames;
+    sa.temperature = e->t_temp;
+    sa.top_k = e->t_top_k;
+    sa.top_p = e->t_top_p;
+    sa.seed = e->seed;
     if (launch_talker_sample(st, sa)) return -1;
     CpFrameIO io;
     io.codes = e->d_codes;
@@ -100,6 +108,9 @@ int frame_chain(Engine* e, hipStream_t st, int row0, int R) {
     io.fb_h = e->wt.h;
     io.fb_ssq = e->wt.ssq;
     io.pad_embed = e->d_pad;
+    io.temperature = e->c_temp;
+    io.top_k = e->c_top_k;
+    io.seed = e->seed ^ 0x5851F42D4C957F2Dull;
     if (cp_frame(st, m, e->wc, e->kv_c, R, io, row0, e->B)) return -1;
     RowMap rm;
     rm.slot = e->d_iota;
@@ -220,6 +231,20 @@ void* q3e_create(const char* weights, int max_batch, int n_ctx, int max_frames) 
         return nullptr;
     }
     return e;
+}
+
+int q3e_set_sampling(void* ee, float talker_temperature, int talker_top_k, float talker_top_p, float cp_temperature,
+                     int cp_top_k, uint64_t seed) {
+    Engine* e = (Engine*)ee;
+    if (!e) return -1;
+    e->t_temp = talker_temperature;
+    e->t_top_k = talker_top_k;
+    e->t_top_p = talker_top_p;
+    e->c_temp = cp_temperature;
+    e->c_top_k = cp_top_k;
+    e->seed = seed;
+    for (auto& g : e->graph) g.reset();  // the captured kernels carry the old parameters
+    return 0;
 }
 
 int q3e_set_chains(void* ee, int n) {

@@ -110,6 +110,10 @@ struct TalkerSampleArgs {
     int ignore_eos = 0;
     int max_frames = 0;
     float rep_penalty = 1.2f;
+    // temperature <= 1e-6: arg-max (the reference's limit); else top-k / temperature / top-p on the device
+    float temperature = 0.f, top_p = 0.95f;
+    int top_k = 50;
+    unsigned long long seed = 0;
 };
 int launch_talker_sample(hipStream_t s, const TalkerSampleArgs& a);
 
@@ -131,6 +135,9 @@ struct CpArgmaxArgs {
     const float* const* cp_tables = nullptr;  // device array [n_groups]
     const float* pad_embed = nullptr;
     int n_groups = 15;
+    float temperature = 0.f;   // <= 1e-6: arg-max
+    int top_k = 50;
+    unsigned long long seed = 0;
 };
 int launch_cp_argmax(hipStream_t s, const CpArgmaxArgs& a);
 

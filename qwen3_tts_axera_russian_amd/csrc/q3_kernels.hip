@@ -323,6 +323,8 @@ static int launch_linear_t(hipStream_t s, const LinArgs& a) {
 }
 
 // (KBW, NW) per K; overridable for tuning through q3_set_linear_tuning().
+static int g_wide_tiles = 0;  // measured no gain on MI355X (4.06 vs 4.12 ms/frame at 32 rows)
+int set_linear_wide_tiles(int on) { g_wide_tiles = on; return 0; }
 static int g_split_rows_narrow = 1;
 int set_linear_split_rows(int on) { g_split_rows_narrow = on; return 0; }
 // k-blocks per wave by [K = 1024, 2048, 3072][rows <= 16, <= 32, more]
@@ -359,13 +361,17 @@ int launch_linear(hipStream_t s, const LinArgs& a, int pro, int epi) {
     if (rows > 16 && rows <= 32 && ((g_split_rows_narrow == 1 && a.N <= 1024) || g_split_rows_narrow == 2)) mt16 = 1;
     const int kbw = g_tune_kbw[ki][mt16 == 1 ? 0 : mt16 == 2 ? 1 : 2];
     const int nw = K / 32 / kbw;
-    const int nb16 = (epi == EPI_SWIGLU) ? 2 : 1;
+    // two column tiles per workgroup halve the activation traffic through L2 (it is the larger stream
+    // once rows > 16); SwiGLU needs the gate/up pair anyway
+    const int nb16 = (epi == EPI_SWIGLU || (g_wide_tiles && rows > 16 && K == 1024 && epi == EPI_STORE)) ? 2 : 1;
     // K = 1024
     Q3_LIN_MT(1, 8, 4, PRO_NORM, EPI_STORE)
     Q3_LIN_MT(1, 4, 8, PRO_NORM, EPI_STORE)
     Q3_LIN_MT(2, 8, 4, PRO_NORM, EPI_SWIGLU)
     Q3_LIN_MT(2, 4, 8, PRO_NORM, EPI_SWIGLU)
     Q3_LIN_MT(1, 8, 4, PRO_F16, EPI_STORE)
+    Q3_LIN_MT(2, 4, 8, PRO_NORM, EPI_STORE)
+    Q3_LIN_MT(2, 4, 8, PRO_F16, EPI_STORE)
     Q3_LIN_MT(1, 4, 8, PRO_F16, EPI_STORE)
     // K = 2048
     Q3_LIN_MT(1, 8, 8, PRO_F16, EPI_RESID)
@@ -753,6 +759,83 @@ __device__ __forceinline__ void block_argmax(float& v, int& idx, float* sv, int*
     __syncthreads();
 }
 
+// ---- stochastic sampling on the device (top-k / temperature / optional top-p) -----------------
+// Counter-based generator: the draw depends only on (seed, row, frame, group), so a captured graph
+// replays deterministically for a given seed.
+__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned row, unsigned frame, unsigned group) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (1ull + row + ((unsigned long long)frame << 20) +
+                                                            ((unsigned long long)group << 44));
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);   // 24 bits -> [0, 1)
+}
+
+// lg: n processed logits in LDS (destroyed).  Picks the top_k largest (ties: lowest index first), applies
+// softmax((l - max) / max(T, 1e-6)) like the reference samplers, optionally keeps the smallest prefix of
+// the descending order whose mass reaches top_p (llamacpp_talker_server.py:199-205), and draws with u.
+// All threads of the block must call it; every thread returns the chosen index.
+__device__ int block_sample_topk(float* lg, int n, int top_k, float temperature, float top_p, float u, float* sv,
+                                 int* si, float* selv, int* seli) {
+    if (top_k > 64) top_k = 64;
+    if (top_k > n) top_k = n;
+    for (int k = 0; k < top_k; k++) {
+        float best = -INFINITY;
+        int bidx = 0x7fffffff;
+        for (int v = threadIdx.x; v < n; v += blockDim.x) {
+            const float l = lg[v];
+            if (l > best) {
+                best = l;
+                bidx = v;
+            }
+        }
+        block_argmax(best, bidx, sv, si);
+        if (threadIdx.x == 0) {
+            selv[k] = best;
+            seli[k] = bidx;
+            lg[bidx] = -INFINITY;
+        }
+        __syncthreads();
+    }
+    // the selection is in descending order: selv[0] is the maximum
+    __shared__ int chosen;
+    if (threadIdx.x == 0) {
+        const float inv_t = 1.0f / fmaxf(temperature, 1e-6f);
+        float sum = 0.f;
+        for (int k = 0; k < top_k; k++) {
+            selv[k] = expf((selv[k] - selv[0]) * inv_t);
+            sum += selv[k];
+        }
+        int keep = top_k;
+        if (top_p > 0.f && top_p < 1.f) {
+            float c = 0.f;
+            keep = top_k;
+            for (int k = 0; k < top_k; k++) {
+                c += selv[k] / sum;
+                if (c >= top_p) {   // np.searchsorted(cumsum, top_p) + 1 entries
+                    keep = k + 1;
+                    break;
+                }
+            }
+            sum = 0.f;
+            for (int k = 0; k < keep; k++) sum += selv[k];
+        }
+        float c = 0.f;
+        int pick = seli[keep - 1];
+        const float target = u * sum;
+        for (int k = 0; k < keep; k++) {
+            c += selv[k];
+            if (target < c) {
+                pick = seli[k];
+                break;
+            }
+        }
+        chosen = pick;
+    }
+    __syncthreads();
+    return chosen;
+}
+
 __global__ void talker_sample_kernel(TalkerSampleArgs a) {
     Q3_TL(42);
     __shared__ float sv[16];
@@ -787,6 +870,10 @@ __global__ void talker_sample_kernel(TalkerSampleArgs a) {
     float best = -INFINITY;
     int bidx = 0x7fffffff;
     const int nw_ = nwin;
+    extern __shared__ float slg[];   // [V] processed logits, only when sampling stochastically
+    __shared__ float selv[64];
+    __shared__ int seli[64];
+    const bool stochastic = a.temperature > 1e-6f;
     for (int v = threadIdx.x; v < a.V; v += blockDim.x) {
         float l = a.logits[(size_t)r * a.V + v];
         if (v >= a.audio_vocab && v != a.eos) l = -1e10f;
@@ -797,12 +884,19 @@ __global__ void talker_sample_kernel(TalkerSampleArgs a) {
         bool rep = false;
         for (int i = 0; i < nw_; i++) rep |= (win[i] == v);
         if (rep) l = l > 0.f ? __fdiv_rn(l, a.rep_penalty) : l * a.rep_penalty;
+        if (stochastic) slg[v] = l;
         if (l > best || (l == best && v < bidx)) {
             best = l;
             bidx = v;
         }
     }
-    block_argmax(best, bidx, sv, si);
+    if (stochastic) {
+        __syncthreads();
+        const float u = uniform01(a.seed, (unsigned)r, (unsigned)a.n_frames[r], 0u);
+        bidx = block_sample_topk(slg, a.V, a.top_k, a.temperature, a.top_p, u, sv, si, selv, seli);
+    } else {
+        block_argmax(best, bidx, sv, si);
+    }
     if (threadIdx.x == 0) {
         int code = bidx;
         if (force_eos && !a.ignore_eos) code = a.eos;
@@ -824,7 +918,8 @@ __global__ void talker_sample_kernel(TalkerSampleArgs a) {
 }
 int launch_talker_sample(hipStream_t s, const TalkerSampleArgs& a) {
     if (a.R <= 0) return 0;
-    hipLaunchKernelGGL(talker_sample_kernel, dim3(a.R), dim3(256), 0, s, a);
+    const size_t lds = a.temperature > 1e-6f ? (size_t)a.V * sizeof(float) : 0;
+    hipLaunchKernelGGL(talker_sample_kernel, dim3(a.R), dim3(256), lds, s, a);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
 }
@@ -922,6 +1017,18 @@ __global__ void __launch_bounds__(256) cp_argmax_kernel(CpArgmaxArgs a) {
             best = sv[i];
             bidx = si[i];
         }
+    if (a.temperature > 1e-6f) {   // code_predictor_server.py:87-92: top-k, softmax((l-max)/T), categorical draw
+        extern __shared__ float slg[];
+        __shared__ float selv[64];
+        __shared__ int seli[64];
+        __shared__ float sv2[16];
+        __shared__ int si2[16];
+        __syncthreads();
+        for (int v = tid; v < a.V; v += 256) slg[v] = a.logits[(size_t)r * a.V + v];
+        __syncthreads();
+        const float u = uniform01(a.seed, (unsigned)r, (unsigned)a.n_frames[r], 1u + (unsigned)a.group);
+        bidx = block_sample_topk(slg, a.V, a.top_k, a.temperature, 0.f, u, sv2, si2, selv, seli);
+    }
     int f = a.n_frames[r] - 1;
     if (f < 0) f = 0;
     if (f >= a.frame_cap) f = a.frame_cap - 1;
@@ -939,7 +1046,8 @@ __global__ void __launch_bounds__(256) cp_argmax_kernel(CpArgmaxArgs a) {
 }
 int launch_cp_argmax(hipStream_t s, const CpArgmaxArgs& a) {
     if (a.R <= 0) return 0;
-    hipLaunchKernelGGL(cp_argmax_kernel, dim3(a.R), dim3(256), 0, s, a);
+    const size_t lds = a.temperature > 1e-6f ? (size_t)a.V * sizeof(float) : 0;
+    hipLaunchKernelGGL(cp_argmax_kernel, dim3(a.R), dim3(256), lds, s, a);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
 }

@@ -34,8 +34,10 @@ struct ConvArgs {
     const float* inv_beta = nullptr;
     const float* res = nullptr;       // [B][Cout][L] added in the epilogue
     int Cin = 0, M = 0, K = 0, dil = 1, Lin = 0, stride = 1, Cout = 0, clamp = 0;
+    int n_tiles = 0, tiles_l = 0, tiles_m = 0;  // set by the launcher
 };
 
+static int g_voc_max_wgs = 0;  // 0 = one workgroup per tile; >0 caps the grid (persistent tile loop)
 constexpr int VKC = 8;     // input channels per LDS stage
 constexpr int VTN = 128;   // output columns per workgroup (4 waves x 32)
 
@@ -43,19 +45,23 @@ template <int MT>
 __global__ void __launch_bounds__(256) conv_kernel(ConvArgs a) {
     constexpr int TM = 32 * MT, TMP = TM + 4;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int l0 = blockIdx.x * VTN, m0 = blockIdx.y * TM, b = blockIdx.z;
     const int halo = (a.K - 1) * a.dil;
+    // persistent over output tiles: the grid may be capped (a.n_tiles > gridDim.x) so that the vocoder
+    // leaves compute units free for a concurrently running latency-bound frame loop
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int lx = tile % a.tiles_l, my = (tile / a.tiles_l) % a.tiles_m, b = tile / (a.tiles_l * a.tiles_m);
+    const int l0 = lx * VTN, m0 = my * TM;
     const int XW = VTN + halo;  // staged columns: l0-halo .. l0+127
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Ws = lds;                      // [K][VKC][TMP]
     float* Xs = lds + a.K * VKC * TMP;    // [VKC][XW]
-    const float* xb = a.x + (size_t)b * a.Cin * a.Lin;
 
     f16v acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[mt][i] = 0.f;
+    const float* xb = a.x + (size_t)b * a.Cin * a.Lin;
 
     for (int ci0 = 0; ci0 < a.Cin; ci0 += VKC) {
         __syncthreads();  // previous stage fully consumed
@@ -121,6 +127,7 @@ __global__ void __launch_bounds__(256) conv_kernel(ConvArgs a) {
                 }
             }
     }
+    }  // tile loop
 }
 
 template <int MT>
@@ -133,8 +140,13 @@ static int launch_conv_t(hipStream_t s, const ConvArgs& a, int B) {
         Q3_HIP(hipFuncSetAttribute((const void*)conv_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256), -1);
         attr = 160 * 1024;
     }
-    dim3 grid((a.Lin + VTN - 1) / VTN, (a.M + TM - 1) / TM, B);
-    hipLaunchKernelGGL((conv_kernel<MT>), grid, dim3(256), lds, s, a);
+    ConvArgs c = a;
+    c.tiles_l = (a.Lin + VTN - 1) / VTN;
+    c.tiles_m = (a.M + TM - 1) / TM;
+    c.n_tiles = c.tiles_l * c.tiles_m * B;
+    int grid = c.n_tiles;
+    if (g_voc_max_wgs > 0 && grid > g_voc_max_wgs) grid = g_voc_max_wgs;
+    hipLaunchKernelGGL((conv_kernel<MT>), dim3(grid), dim3(256), lds, s, c);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
 }
@@ -418,6 +430,12 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
     }
     v->h_chunk.resize((size_t)v->chunk * v->upsample);
     return v;
+}
+
+// Cap the number of workgroups every vocoder launch may occupy (0 = no cap).  Process-wide.
+int voc_set_max_workgroups(int n) {
+    g_voc_max_wgs = n < 0 ? 0 : n;
+    return 0;
 }
 
 int voc_chunk_tokens(void* vv) { return vv ? ((Voc*)vv)->chunk : 0; }

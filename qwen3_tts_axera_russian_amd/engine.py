@@ -18,6 +18,12 @@ class FrameEngine:
         self.max_batch, self.n_ctx, self.max_frames = max_batch, n_ctx, max_frames
         self.B = 0
 
+    def set_sampling(self, talker_temperature=0.0, talker_top_k=50, talker_top_p=0.95, cp_temperature=0.0,
+                     cp_top_k=50, seed=0):
+        if self._lib.q3e_set_sampling(self.h, float(talker_temperature), int(talker_top_k), float(talker_top_p),
+                                      float(cp_temperature), int(cp_top_k), int(seed)) != 0:
+            raise RuntimeError("q3e_set_sampling failed")
+
     def set_chains(self, n):
         if self._lib.q3e_set_chains(self.h, int(n)) != 0:
             raise RuntimeError("q3e_set_chains failed")

@@ -62,6 +62,7 @@ def load(path: str | None = None):
     _sig(lib, "q3e_free", None, [c_void_p])
     _sig(lib, "q3e_set_pad_embed", c_int, [c_void_p, f32p])
     _sig(lib, "q3e_set_chains", c_int, [c_void_p, c_int])
+    _sig(lib, "q3e_set_sampling", c_int, [c_void_p, c_float, c_int, c_float, c_float, c_int, ctypes.c_uint64])
     _sig(lib, "q3e_start", c_int, [c_void_p, c_int, f32p, i32p, i32p, c_int, c_int])
     _sig(lib, "q3e_run", c_int, [c_void_p, c_int])
     _sig(lib, "q3e_last_run_ms", c_float, [c_void_p])
@@ -78,6 +79,7 @@ def load(path: str | None = None):
     _sig(lib, "voc_synthesize", c_int, [c_void_p, i64p, c_int, i16p, i32p])
     _sig(lib, "voc_synthesize_f32", c_int, [c_void_p, i64p, c_int, f32p, i32p])
     _sig(lib, "voc_synthesize_max_samples", c_int, [c_void_p, c_int])
+    _sig(lib, "voc_set_max_workgroups", c_int, [c_int])
     _sig(lib, "voc_last_decode_ms", c_float, [c_void_p])
     _sig(lib, "voc_decode_flops", ctypes.c_double, [c_void_p, c_int])
     # test hooks
@@ -88,6 +90,7 @@ def load(path: str | None = None):
                                     f32p, f32p, u16p, c_int])
     _sig(lib, "q3t_talker_sample", c_int, [f32p, c_int, i32p, c_int, c_int, c_int])
     _sig(lib, "q3t_set_linear_split_rows", c_int, [c_int])
+    _sig(lib, "q3t_set_linear_wide_tiles", c_int, [c_int])
     _sig(lib, "q3t_bench_linear", c_float, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int])
     if path is None:
         _lib = lib

@@ -85,3 +85,41 @@ def test_cp_batch_equals_single(gpu_lib, setup):
     with pytest.raises(RuntimeError):
         cpb.predict_batch(np.zeros((9, 1024), np.float32), np.zeros(9, np.int32))
     cpb.destroy()
+
+
+def test_cp_stochastic_sampling_distribution(gpu_lib, setup):
+    """temperature > 0: group-0 tokens drawn on the device follow the reference sampler's distribution
+    (code_predictor_server.py:87-92: top-k 50, softmax((l-max)/T)); only the random stream differs."""
+    path, cfg, tensors, ref = setup
+    cp = CodePredictor(path, max_batch=32)
+    rng = np.random.default_rng(21)
+    hidden = rng.standard_normal(1024).astype(np.float32)
+    code0 = 77
+    # logits of group 0 from the oracle, then the reference's distribution
+    codes, margins, hid = ref.predict(hidden, code0, want_hidden=True)
+    from oracle import oracle as orc
+    logits = orc.head_logits(ref.heads[0], hid[0])
+    T, K = 0.5, 50
+    top = np.argsort(logits)[-K:]
+    p = np.exp((logits[top] - logits[top].max()) / T)
+    p /= p.sum()
+    want = dict(zip(top.tolist(), p.tolist()))
+    counts, N = {}, 0
+    H = np.tile(hidden, (32, 1))
+    C0 = np.full(32, code0, np.int32)
+    for seed in range(1, 65):
+        got = cp.predict_batch(H, C0, temperature=T, top_k=K, seed=seed)
+        for tok in got[:, 0]:
+            counts[int(tok)] = counts.get(int(tok), 0) + 1
+            N += 1
+    assert set(counts) <= set(want), "a token outside the top-k was drawn"
+    tv = 0.5 * sum(abs(counts.get(t, 0) / N - want[t]) for t in want)
+    print("total variation distance over", N, "draws:", tv)
+    assert tv < 0.08
+    # reproducible per seed, different across seeds, and T -> 0 is the arg-max
+    a = cp.predict_batch(H[:4], C0[:4], temperature=T, top_k=K, seed=5)
+    b = cp.predict_batch(H[:4], C0[:4], temperature=T, top_k=K, seed=5)
+    np.testing.assert_array_equal(a, b)
+    g = cp.predict_batch(H[:1], C0[:1], temperature=0.0)
+    assert list(g[0]) == [int(x) for x in codes] or margins.min() < 1e-4
+    cp.destroy()
