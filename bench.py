@@ -160,6 +160,27 @@ def kv_bytes_per_step(n_text, frames, cfg):
     return sum(per_pos * t for t in t_avg) + cp * len(n_text)
 
 
+# HBM bytes per launch of the gate/up kernel from the PMC counters (profiles/r01_pmc_linear.md: FETCH_SIZE
+# doubled as the gfx950 guide prescribes + WRITE_SIZE), keyed by the row count it was collected at
+PMC_TRAFFIC_GATEUP = {32: 13.80e6 + 0.197e6, 1: 12.71e6 + 0.006e6}
+
+
+def dominant_kernel_roofline(lib, rows):
+    """The dominant kernel of the path by bytes: the fused RMSNorm -> gate/up GEMM -> SwiGLU launch
+    (12.58 MB of fp16 weights, 36 % of a layer's stream).  Timed live: back-to-back launches over 48
+    distinct weight copies (cold, like the layer walk), HIP events on the launch stream."""
+    import ctypes
+    lib.q3t_bench_linear.restype = ctypes.c_float
+    N, K = 6144, 1024
+    us = float(lib.q3t_bench_linear(int(rows), N, K, 1, 2, 1, 48, 480))
+    algo = N * K * 2 + rows * K * 4 + rows * (N // 2) * 2      # weights + f32 activations in + fp16 out
+    ach = algo / (us * 1e-6) / 1e9
+    return {"kernel": "linear_kernel<gate/up+SwiGLU> (RMSNorm prologue, MFMA 16x16x32 f16, split-K over waves)",
+            "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC_GATEUP.get(int(rows)),
+            "algorithmic_bytes_per_launch": int(algo), "avg_launch_us": round(us, 3), "rows": int(rows)}
+
+
 def cpu_baseline(path, cfg, prefix, n_text, pad, frames):
     """The CPU restatement (oracle/, the 'port' baseline) on a bounded sample of the same workload."""
     from oracle import oracle as orc
@@ -275,10 +296,11 @@ def main():
         "rtf": round((dt / a.steps) / (F * FRAME_SEC), 5),
         "rtf_aggregate": round((dt / a.steps) / (world * B * F * FRAME_SEC), 6),
         "prefill_ms": round(prefill_ms, 3), "vocoder_ms_per_step": round(voc_ms, 3),
-        "roofline": {"kernel": "frame-step hipGraph (talker 28L + 16 CP passes + heads)", "bound": "hbm",
-                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(frame_ms, 4)},
+        "roofline": dominant_kernel_roofline(lib, B),
+        "roofline_step": {"kernel": "frame-step hipGraph (talker 28L + 16 CP passes + heads, 560 nodes)",
+                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                          "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(frame_ms, 4)},
     }
     if voc is not None:
         fl = float(lib.voc_decode_flops(voc.h, B))
