@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(NW * 64) linear_kernel(LinArgs a) {
                 }
                 const int m = m0 + mr;
                 if (m < a.M) {
-                    const float sg = g / (1.0f + expf(-g));
+                    const float sg = __fdividef(g, 1.0f + __expf(-g));   // hardware exp/rcp: ~1e-6 relative, far below the fp16 rounding that follows
                     a.act[(size_t)m * (a.N / 2) + (size_t)(tile0 / NB16) * NH + j] = sat_half(sg * u);
                 }
             }
@@ -620,8 +620,8 @@ __global__ void __launch_bounds__(1024) attn_kernel(AttnArgs a) {
             d1 += __shfl_xor(d1, o, 16);
         }
         const float n0 = fmaxf(m0, d0), n1 = fmaxf(m1, d1);
-        const float c0 = expf(m0 - n0), c1 = expf(m1 - n1);   // exp(-inf) = 0 on the first row
-        const float p0 = expf(d0 - n0), p1 = expf(d1 - n1);
+        const float c0 = __expf(m0 - n0), c1 = __expf(m1 - n1);   // exp(-inf) = 0 on the first row
+        const float p0 = __expf(d0 - n0), p1 = __expf(d1 - n1);
         l0 = l0 * c0 + p0;
         l1 = l1 * c1 + p1;
 #pragma unroll
@@ -660,8 +660,8 @@ __global__ void __launch_bounds__(1024) attn_kernel(AttnArgs a) {
         const float ol0 = __shfl_xor(l0, o, 64), ol1 = __shfl_xor(l1, o, 64);
         const float n0 = fmaxf(m0, om0), n1 = fmaxf(m1, om1);
         // a group that saw no row has m = -inf and l = 0: its scale is exp(-inf - n) = 0 unless n is -inf too
-        const float c0 = (m0 == -INFINITY) ? 0.f : expf(m0 - n0), d0 = (om0 == -INFINITY) ? 0.f : expf(om0 - n0);
-        const float c1 = (m1 == -INFINITY) ? 0.f : expf(m1 - n1), d1 = (om1 == -INFINITY) ? 0.f : expf(om1 - n1);
+        const float c0 = (m0 == -INFINITY) ? 0.f : __expf(m0 - n0), d0 = (om0 == -INFINITY) ? 0.f : __expf(om0 - n0);
+        const float c1 = (m1 == -INFINITY) ? 0.f : __expf(m1 - n1), d1 = (om1 == -INFINITY) ? 0.f : __expf(om1 - n1);
         l0 = l0 * c0 + ol0 * d0;
         l1 = l1 * c1 + ol1 * d1;
 #pragma unroll
@@ -694,7 +694,7 @@ __global__ void __launch_bounds__(1024) attn_kernel(AttnArgs a) {
         float L = 0.f, o = 0.f;
         for (int i = 0; i < nwv; i++) {
             const float mi = pm[i * 2 + hh];
-            const float c = (mi == -INFINITY) ? 0.f : expf(mi - M);
+            const float c = (mi == -INFINITY) ? 0.f : __expf(mi - M);
             L += pl[i * 2 + hh] * c;
             o += pacc[(i * 2 + hh) * D + d] * c;
         }

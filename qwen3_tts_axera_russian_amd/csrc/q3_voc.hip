@@ -41,129 +41,144 @@ static int g_voc_max_wgs = 0;  // 0 = one workgroup per tile; >0 caps the grid (
 constexpr int VKC = 8;     // input channels per LDS stage
 constexpr int VTN = 128;   // output columns per workgroup (4 waves x 32)
 
-template <int MT>
+// conv_kernel<MT, KT, KC>: MT 32-row MFMA tiles per wave, KT taps, KC input channels per LDS stage.
+// Staging goes global -> LDS directly; ~4 workgroups per CU hide its latency (a register-staged software
+// pipeline was tried: 199-256 VGPRs, one workgroup per SIMD, 1.6x slower at 32 chunks).
+template <int MT, int KT, int KC>
 __global__ void __launch_bounds__(256) conv_kernel(ConvArgs a) {
-    constexpr int TM = 32 * MT, TMP = TM + 4;
+    constexpr int TM = 32 * MT, TMP = TM + 4, Q = KC / 4;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int halo = (a.K - 1) * a.dil;
-    // persistent over output tiles: the grid may be capped (a.n_tiles > gridDim.x) so that the vocoder
-    // leaves compute units free for a concurrently running latency-bound frame loop
-    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-    const int lx = tile % a.tiles_l, my = (tile / a.tiles_l) % a.tiles_m, b = tile / (a.tiles_l * a.tiles_m);
-    const int l0 = lx * VTN, m0 = my * TM;
+    const int halo = (KT - 1) * a.dil;
     const int XW = VTN + halo;  // staged columns: l0-halo .. l0+127
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Ws = lds;                      // [K][VKC][TMP]
-    float* Xs = lds + a.K * VKC * TMP;    // [VKC][XW]
-
-    f16v acc[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-        for (int i = 0; i < 16; i++) acc[mt][i] = 0.f;
-    const float* xb = a.x + (size_t)b * a.Cin * a.Lin;
-
-    for (int ci0 = 0; ci0 < a.Cin; ci0 += VKC) {
-        __syncthreads();  // previous stage fully consumed
-        // weights of all K taps for this channel slice: global [k][m][ci] (8 contiguous ci) -> Ws[k][ci][m]
-        for (int idx = tid; idx < a.K * TM * 2; idx += 256) {
-            const int half = idx & 1, mm = (idx >> 1) % TM, k = (idx >> 1) / TM;
-            const int m = m0 + mm;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < a.M) v = *(const float4*)(a.wk + ((size_t)k * a.M + m) * a.Cin + ci0 + half * 4);
-            float* d = Ws + (k * VKC + half * 4) * TMP + mm;
-            d[0] = v.x;
-            d[TMP] = v.y;
-            d[2 * TMP] = v.z;
-            d[3 * TMP] = v.w;
-        }
-        // the input line buffer (causal: columns left of 0 are zero; Snake(0) = 0 so padding commutes)
-        for (int idx = tid; idx < VKC * XW; idx += 256) {
-            const int ci = idx / XW, col = idx % XW;
-            const int l = l0 - halo + col;
-            float v = 0.f;
-            if (l >= 0 && l < a.Lin) {
-                v = xb[(size_t)(ci0 + ci) * a.Lin + l];
-                if (a.alpha) {
-                    const float sn = sinf(a.alpha[ci0 + ci] * v);
-                    v = v + a.inv_beta[ci0 + ci] * (sn * sn);
-                }
-            }
-            Xs[ci * XW + col] = v;
-        }
-        __syncthreads();
-        for (int k = 0; k < a.K; k++) {
-            const int off = halo - (a.K - 1 - k) * a.dil + w * 32 + (lane & 31);
-#pragma unroll
-            for (int kk = 0; kk < VKC; kk += 2) {
-                const int ci = kk + (lane >> 5);
-                const float bv = Xs[ci * XW + off];
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++) {
-                    const float av = Ws[(k * VKC + ci) * TMP + mt * 32 + (lane & 31)];
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt], 0, 0, 0);
-                }
-            }
-        }
-    }
-    // epilogue.  D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const int l = l0 + w * 32 + (lane & 31);
-    const int Lout = a.Lin * a.stride;
-    if (l < a.Lin) {
+    float* Ws = lds;                   // [KT][KC][TMP]
+    float* Xs = lds + KT * KC * TMP;   // [KC][XW]
+    // persistent over output tiles (the grid may be capped, see voc_set_max_workgroups)
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int lx = tile % a.tiles_l, my = (tile / a.tiles_l) % a.tiles_m, b = tile / (a.tiles_l * a.tiles_m);
+        const int l0 = lx * VTN, m0 = my * TM;
+        const float* xb = a.x + (size_t)b * a.Cin * a.Lin;
+        f16v acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < a.M) {
-                    const int co = a.stride == 1 ? m : m / a.stride;
-                    const int p = a.stride == 1 ? 0 : m % a.stride;
-                    const size_t idx = ((size_t)b * a.Cout + co) * Lout + (size_t)l * a.stride + p;
-                    float v = acc[mt][r];
-                    if (a.bias) v += a.bias[co];
-                    if (a.res) v += a.res[idx];
-                    if (a.clamp) v = fminf(fmaxf(v, -1.f), 1.f);
-                    a.y[idx] = v;
+            for (int i = 0; i < 16; i++) acc[mt][i] = 0.f;
+        for (int ci0 = 0; ci0 < a.Cin; ci0 += KC) {
+            __syncthreads();  // previous stage (or tile) fully consumed
+            // stage the weights of all taps for KC channels: global [k][m][ci] -> Ws[k][ci][m]
+            for (int idx = tid; idx < KT * TM * Q; idx += 256) {
+                const int qq = idx % Q, mm = (idx / Q) % TM, k = idx / (Q * TM);
+                const int m = m0 + mm;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < a.M) v = *(const float4*)(a.wk + ((size_t)k * a.M + m) * a.Cin + ci0 + qq * 4);
+                float* d = Ws + (k * KC + qq * 4) * TMP + mm;
+                d[0] = v.x;
+                d[TMP] = v.y;
+                d[2 * TMP] = v.z;
+                d[3 * TMP] = v.w;
+            }
+            // the input line buffer (causal: columns left of 0 are zero; Snake(0) = 0 so padding commutes)
+            for (int idx = tid; idx < KC * XW; idx += 256) {
+                const int ci = idx / XW, col = idx - ci * XW;
+                const int l = l0 - halo + col;
+                float v = 0.f;
+                if (l >= 0 && l < a.Lin) {
+                    v = xb[(size_t)(ci0 + ci) * a.Lin + l];
+                    if (a.alpha) {
+                        const float sn = __sinf(a.alpha[ci0 + ci] * v);
+                        v = v + a.inv_beta[ci0 + ci] * (sn * sn);
+                    }
+                }
+                Xs[idx] = v;
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int k = 0; k < KT; k++) {
+                const int off = halo - (KT - 1 - k) * a.dil + w * 32 + (lane & 31);
+#pragma unroll
+                for (int kk = 0; kk < KC; kk += 2) {
+                    const int ci = kk + (lane >> 5);
+                    const float bv = Xs[ci * XW + off];
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) {
+                        const float av = Ws[(k * KC + ci) * TMP + mt * 32 + (lane & 31)];
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt], 0, 0, 0);
+                    }
                 }
             }
-    }
+        }
+        // epilogue.  D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+        const int l = l0 + w * 32 + (lane & 31);
+        const int Lout = a.Lin * a.stride;
+        if (l < a.Lin) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (m < a.M) {
+                        const int co = a.stride == 1 ? m : m / a.stride;
+                        const int p = a.stride == 1 ? 0 : m % a.stride;
+                        const size_t idx = ((size_t)b * a.Cout + co) * Lout + (size_t)l * a.stride + p;
+                        float v = acc[mt][r];
+                        if (a.bias) v += a.bias[co];
+                        if (a.res) v += a.res[idx];
+                        if (a.clamp) v = fminf(fmaxf(v, -1.f), 1.f);
+                        a.y[idx] = v;
+                    }
+                }
+        }
     }  // tile loop
 }
 
-template <int MT>
+template <int MT, int KT, int KC>
 static int launch_conv_t(hipStream_t s, const ConvArgs& a, int B) {
     constexpr int TM = 32 * MT, TMP = TM + 4;
-    const int halo = (a.K - 1) * a.dil;
-    const size_t lds = ((size_t)a.K * VKC * TMP + (size_t)VKC * (VTN + halo)) * sizeof(float);
-    static size_t attr = 0;
-    if (lds > attr && lds > 48 * 1024) {
-        Q3_HIP(hipFuncSetAttribute((const void*)conv_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256), -1);
-        attr = 160 * 1024;
+    const int halo = (KT - 1) * a.dil;
+    if (a.dil > 9) {
+        Q3_LOG("voc conv: dilation %d > 9 is not built", a.dil);
+        return -1;
     }
+    const size_t lds = ((size_t)KT * KC * TMP + (size_t)KC * (VTN + halo)) * sizeof(float);
     ConvArgs c = a;
     c.tiles_l = (a.Lin + VTN - 1) / VTN;
     c.tiles_m = (a.M + TM - 1) / TM;
     c.n_tiles = c.tiles_l * c.tiles_m * B;
     int grid = c.n_tiles;
     if (g_voc_max_wgs > 0 && grid > g_voc_max_wgs) grid = g_voc_max_wgs;
-    hipLaunchKernelGGL((conv_kernel<MT>), dim3(grid), dim3(256), lds, s, c);
+    hipLaunchKernelGGL((conv_kernel<MT, KT, KC>), dim3(grid), dim3(256), lds, s, c);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
 }
 
-static int launch_conv(hipStream_t s, const ConvArgs& a, int B) {
-    if (a.Cin % VKC) {
-        Q3_LOG("voc conv: Cin=%d is not a multiple of %d", a.Cin, VKC);
-        return -1;
-    }
+template <int KT, int KC>
+static int launch_conv_mt(hipStream_t s, const ConvArgs& a, int B) {
     const int t32 = (a.M + 31) / 32;  // 32-row MFMA tiles needed
     int mt = 4;
     if (t32 % 4 != 0) mt = (t32 % 3 == 0) ? 3 : (t32 % 2 == 0) ? 2 : (t32 < 4 ? t32 : 4);
     switch (mt) {
-        case 1: return launch_conv_t<1>(s, a, B);
-        case 2: return launch_conv_t<2>(s, a, B);
-        case 3: return launch_conv_t<3>(s, a, B);
-        default: return launch_conv_t<4>(s, a, B);
+        case 1: return launch_conv_t<1, KT, KC>(s, a, B);
+        case 2: return launch_conv_t<2, KT, KC>(s, a, B);
+        case 3: return launch_conv_t<3, KT, KC>(s, a, B);
+        default: return launch_conv_t<4, KT, KC>(s, a, B);
+    }
+}
+
+static int launch_conv(hipStream_t s, const ConvArgs& a, int B) {
+    const int c = a.Cin;
+    if (c % 8) {
+        Q3_LOG("voc conv: Cin=%d is not a multiple of 8", c);
+        return -1;
+    }
+    // few taps: deeper channel stages keep enough MFMAs between barriers
+    switch (a.K) {
+        case 1: return c % 32 == 0 ? launch_conv_mt<1, 32>(s, a, B) : c % 16 == 0 ? launch_conv_mt<1, 16>(s, a, B) : launch_conv_mt<1, 8>(s, a, B);
+        case 2: return c % 32 == 0 ? launch_conv_mt<2, 32>(s, a, B) : c % 16 == 0 ? launch_conv_mt<2, 16>(s, a, B) : launch_conv_mt<2, 8>(s, a, B);
+        case 3: return c % 16 == 0 ? launch_conv_mt<3, 16>(s, a, B) : launch_conv_mt<3, 8>(s, a, B);
+        case 7: return launch_conv_mt<7, 8>(s, a, B);
+        default:
+            Q3_LOG("voc conv: kernel with %d taps is not built (1, 2, 3, 7 are)", a.K);
+            return -1;
     }
 }
 
