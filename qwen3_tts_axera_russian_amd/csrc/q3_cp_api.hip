@@ -168,7 +168,7 @@ int cp_predict_batch(void* hh, const float* hidden, const int32_t* code_0, int n
         for (int j = 1; j < 16; j++) h->h_codes[(size_t)r * 16 + j] = -1;
     }
     Q3_HIP(hipMemcpyAsync(h->d_codes, h->h_codes.data(), sizeof(int) * 16 * R, hipMemcpyHostToDevice, h->s), -1);
-    Q3_HIP(hipMemcpyAsync(h->w.h, hidden, sizeof(float) * (size_t)R * H, hipMemcpyHostToDevice, h->s), -1);
+    Q3_HIP(hipMemcpyAsync(h->w.rows_in, hidden, sizeof(float) * (size_t)R * H, hipMemcpyHostToDevice, h->s), -1);
     CpFrameIO io;
     io.codes = h->d_codes;
     io.n_frames = h->d_nframes;
@@ -177,7 +177,7 @@ int cp_predict_batch(void* hh, const float* hidden, const int32_t* code_0, int n
     io.top_k = top_k;
     io.seed = seed;
     auto body = [&]() -> int {
-        if (launch_ssq_rows(h->s, h->w.h, h->w.ssq, R, H)) return -1;
+        if (launch_ssq_rows(h->s, h->w.rows_in, h->w.h, h->w.ssq, R, H)) return -1;
         return cp_frame(h->s, m, h->w, h->kv, R, io);
     };
     if (stochastic) {
@@ -217,8 +217,8 @@ int cp_step(void* hh, const float* embed, int position, float* out_hidden) {
     const Model& m = *h->m;
     const int H = m.cfg.hidden;
     if (position < 0 || position > m.cfg.cp_groups) return -1;
-    Q3_HIP(hipMemcpyAsync(h->w.h, embed, sizeof(float) * H, hipMemcpyHostToDevice, h->s), -1);
-    if (launch_ssq_rows(h->s, h->w.h, h->w.ssq, 1, H)) return -1;
+    Q3_HIP(hipMemcpyAsync(h->w.rows_in, embed, sizeof(float) * H, hipMemcpyHostToDevice, h->s), -1);
+    if (launch_ssq_rows(h->s, h->w.rows_in, h->w.h, h->w.ssq, 1, H)) return -1;
     RowMap rm;
     rm.pos_base = position;
     if (run_stack(h->s, m, m.cp, h->w, h->kv, 1, rm, 256)) return -1;
@@ -243,9 +243,9 @@ int cp_lm_head(void* hh, int group, const float* hidden, float* logits_out) {
     const Model& m = *h->m;
     const int H = m.cfg.hidden, V = m.cfg.cp_vocab;
     if (group < 0 || group >= m.cfg.cp_groups) return -1;
-    std::vector<uint16_t> h16(H);
-    for (int i = 0; i < H; i++) h16[i] = f2h_sat(hidden[i]);
-    Q3_HIP(hipMemcpyAsync(h->w.hidden_f16, h16.data(), H * 2, hipMemcpyHostToDevice, h->s), -1);
+    std::vector<uint16_t> h16((size_t)16 * H, 0);
+    for (int i = 0; i < H; i++) h16[frag_idx_host(0, i, H)] = f2h_sat(hidden[i]);
+    Q3_HIP(hipMemcpyAsync(h->w.hidden_f16, h16.data(), h16.size() * 2, hipMemcpyHostToDevice, h->s), -1);
     LinArgs a;
     a.wp = m.cp_head[group].wp;
     a.N = V;

@@ -119,7 +119,11 @@ int frame_chain(Engine* e, hipStream_t st, int row0, int R) {
     return talker_tail(e, st, row0, R);
 }
 
-int n_chains_eff(const Engine* e) { return e->n_chains > e->B ? e->B : (e->n_chains < 1 ? 1 : e->n_chains); }
+int n_chains_eff(const Engine* e) {
+    // chains own contiguous row ranges that must start on a 16-row fragment block
+    const int nc = e->n_chains < 1 ? 1 : e->n_chains;
+    return (nc > 1 && e->B % (16 * nc) == 0) ? nc : 1;
+}
 
 void chain_rows(const Engine* e, int c, int& row0, int& R) {
     const int nc = n_chains_eff(e);
@@ -313,11 +317,11 @@ int q3e_start(void* ee, int B, const float* prefix, const int32_t* n_rows, const
             }
             last[b] = r - 1;
         }
-        Q3_HIP(hipMemcpyAsync(e->wt.h, prefix + row_off * H, sizeof(float) * (size_t)rows * H, hipMemcpyHostToDevice, e->s), -1);
+        Q3_HIP(hipMemcpyAsync(e->wt.rows_in, prefix + row_off * H, sizeof(float) * (size_t)rows * H, hipMemcpyHostToDevice, e->s), -1);
         Q3_HIP(hipMemcpyAsync(e->d_slot, slot.data(), sizeof(int) * rows, hipMemcpyHostToDevice, e->s), -1);
         Q3_HIP(hipMemcpyAsync(e->d_pos, pos.data(), sizeof(int) * rows, hipMemcpyHostToDevice, e->s), -1);
         Q3_HIP(hipMemcpyAsync(e->d_lastrow + b0, last.data() + b0, sizeof(int) * (b1 - b0), hipMemcpyHostToDevice, e->s), -1);
-        if (launch_ssq_rows(e->s, e->wt.h, e->wt.ssq, rows, H)) return -1;
+        if (launch_ssq_rows(e->s, e->wt.rows_in, e->wt.h, e->wt.ssq, rows, H)) return -1;
         RowMap rm;
         rm.slot = e->d_slot;
         rm.pos = e->d_pos;
@@ -332,12 +336,13 @@ int q3e_start(void* ee, int B, const float* prefix, const int32_t* n_rows, const
             f.gamma = m.talker.final_norm;
             f.eps = m.cfg.eps;
             f.R = b1 - b0;
+            f.row0 = b0;   // output rows b0..b1-1 (fragment-ordered buffers are indexed, not offset)
             f.H = H;
-            f.row_map = e->d_lastrow + b0;
-            f.out_f32 = e->wt.hidden_f32 + (size_t)b0 * H;
-            f.out_f16 = e->wt.hidden_f16 + (size_t)b0 * H;
-            f.out_copy = e->wc.h + (size_t)b0 * H;
-            f.out_copy_ssq = e->wc.ssq + (size_t)b0 * (H / 16);
+            f.row_map = e->d_lastrow;
+            f.out_f32 = e->wt.hidden_f32;
+            f.out_f16 = e->wt.hidden_f16;
+            f.out_copy = e->wc.h;
+            f.out_copy_ssq = e->wc.ssq;
             if (launch_final_norm(e->s, f)) return -1;
         }
         Q3_HIP(hipStreamSynchronize(e->s), -1);  // host staging vectors are reused by the next group

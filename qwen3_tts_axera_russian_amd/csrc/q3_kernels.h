@@ -19,6 +19,7 @@ struct LinArgs {
     int m_begin = 0;
     int swap_grid = 0;  // set by the launcher
     int nt = 0;  // 1: stream the weights with non-temporal loads (read once per step: talker)
+    // A operands are stored in MFMA fragment order (frag_idx), buffers padded to 16 rows.
     // prologue PRO_F16: A = x16[M][K] (fp16).  PRO_NORM: A = fp16((h*inv)*gamma),
     // inv[m] = 1/sqrt(sum(ssq[m][0..ssq_parts))/K + eps).
     const half_t* x16 = nullptr;
@@ -64,8 +65,9 @@ struct AttnArgs {
 };
 int launch_attn(hipStream_t s, const AttnArgs& a, int mode);
 
-// ssq[m][p] = sum_{k in 16-block p} h[m][k]^2  (H/16 partials per row)
-int launch_ssq_rows(hipStream_t s, const float* h, float* ssq, int R, int H);
+// Uploaded row-major rows[R][H] -> residual stream h in fragment order (see frag_idx in q3_kernels.hip)
+// + ssq[m][p] = sum_{k in 16-block p} rows[m][k]^2  (H/16 partials per row)
+int launch_ssq_rows(hipStream_t s, const float* rows, float* h, float* ssq, int R, int H);
 
 // hidden = (h*inv)*gamma per row; optional outputs: f32 hidden, fp16 hidden,
 // a second f32 copy (+ its ssq partials) that seeds the code predictor.
@@ -76,7 +78,8 @@ struct FinalNormArgs {
     const float* gamma = nullptr;
     float eps = 1e-6f;
     int R = 0, H = 0, row0 = 0;    // output rows row0 .. row0+R-1
-    const int* row_map = nullptr;  // optional: source row of output row r
+    const int* row_map = nullptr;  // optional: source row of output row r (indexed by the output row)
+    int src_off = 0;               // without a map: source row = output row + src_off
     float* out_f32 = nullptr;
     half_t* out_f16 = nullptr;
     float* out_copy = nullptr;

@@ -25,7 +25,8 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ unsigned long long* g_tl = nullptr;   // [cap][2] start/end stamps (100 MHz wall clock)
 __device__ unsigned int g_tl_idx = 0;
 __device__ unsigned int g_tl_cap = 0;
-__device__ int g_skip = 0;   // diagnostic: every kernel returns at once (measures the pure dispatch chain)
+__device__ int g_skip = 0;
+__device__ unsigned long long* g_ph = nullptr;  // [cap][8] phase stamps of block 0 (shader clock)   // diagnostic: every kernel returns at once (measures the pure dispatch chain)
 struct TlScope {
     unsigned int slot = 0xffffffffu;
     int id;
@@ -42,8 +43,13 @@ struct TlScope {
 #define Q3_TL(id)      \
     if (g_skip) return; \
     TlScope tl_scope_(id)
+#define Q3_PH(n)                                                                                       \
+    do {                                                                                               \
+        if (tl_scope_.slot < g_tl_cap && g_ph) g_ph[(size_t)tl_scope_.slot * 8 + (n)] = wall_clock64(); \
+    } while (0)
 #else
 #define Q3_TL(id)
+#define Q3_PH(n)
 #endif
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -58,6 +64,16 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 __device__ __forceinline__ half_t sat_half(float x) {
     return (half_t)fminf(fmaxf(x, -65504.f), 65504.f);
+}
+
+// Activations that feed a GEMM (residual stream h, attention output, SwiGLU output) live in MFMA
+// A-fragment order, like the weights: 16-row x 32-k blocks (mt = m/16, kb = k/32), inside a block lane
+// (m%16) + 16*((k%32)/8) owns 8 consecutive k.  A wave's fragment load is then 64 lanes x 16 B (fp16) or
+// 2 x 64 x 16 B (f32) of CONTIGUOUS memory instead of 16 rows x 4 KB apart (measured: 3-4 us just to issue
+// the uncoalesced loads of a 32-row tile).  Element (m, k) of a [rows][K] matrix sits at frag_idx(m, k, K);
+// groups of 8 consecutive k (k % 8 == 0) stay contiguous, so float4 / 8-byte row accesses still work.
+__device__ __forceinline__ size_t frag_idx(int m, int k, int K) {
+    return ((((size_t)(m >> 4) * (K >> 5) + (k >> 5)) * 64 + (m & 15) + 16 * ((k >> 3) & 3)) << 3) + (k & 7);
 }
 
 // ---------------------------------------------------------------------------
@@ -147,7 +163,7 @@ __global__ void __launch_bounds__(NW * 64) linear_kernel(LinArgs a) {
             const int o = tid + i * NTH;
             const int m = m0 + o / NB;
             hold[i] = 0.f;
-            if (o < NOUT && m < a.M) hold[i] = a.h_out[(size_t)m * a.N + tile0 * 16 + (o % NB)];
+            if (o < NOUT && m < a.M) hold[i] = a.h_out[frag_idx(m, tile0 * 16 + (o % NB), a.N)];
         }
     }
     // (b) the weight stream (HBM, the long pole): everything this wave will need, in flight at once
@@ -168,10 +184,10 @@ __global__ void __launch_bounds__(NW * 64) linear_kernel(LinArgs a) {
             graw[kbi][1] = *(const float4*)(a.gamma + k0 + 4);
 #pragma unroll
             for (int mt = 0; mt < MT16; mt++) {
-                int m = m0 + mt * 16 + c;
-                if (m >= a.M) m = a.M - 1;  // padded rows recompute a valid row; never stored
-                hraw[mt][kbi][0] = *(const float4*)(a.h + (size_t)m * K + k0);
-                hraw[mt][kbi][1] = *(const float4*)(a.h + (size_t)m * K + k0 + 4);
+                // rows beyond a.M are padding of the last 16-row block (allocated, never stored from)
+                const float* hp = a.h + frag_idx(m0 + mt * 16 + c, k0, K);
+                hraw[mt][kbi][0] = *(const float4*)(hp);
+                hraw[mt][kbi][1] = *(const float4*)(hp + 4);
             }
         }
     } else {
@@ -180,13 +196,12 @@ __global__ void __launch_bounds__(NW * 64) linear_kernel(LinArgs a) {
             const int k0 = (w * KBW + kbi) * 32 + q * 8;
 #pragma unroll
             for (int mt = 0; mt < MT16; mt++) {
-                int m = m0 + mt * 16 + c;
-                if (m >= a.M) m = a.M - 1;
-                af[mt][kbi] = *(const h8*)(a.x16 + (size_t)m * K + k0);
+                af[mt][kbi] = *(const h8*)(a.x16 + frag_idx(m0 + mt * 16 + c, k0, K));
             }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    Q3_PH(0);  // all loads issued
 
     // ---- 2. RMSNorm scale per row from the producer's 64 sum-of-squares partials (a.ssq_parts == 64) ----
     if (PRO == PRO_NORM) {
@@ -221,6 +236,7 @@ __global__ void __launch_bounds__(NW * 64) linear_kernel(LinArgs a) {
             }
     }
 
+    Q3_PH(1);  // prologue done (norm scale known, activations converted)
     // ---- 3. MFMA over this wave's K slice ----
     f4 acc[MT16][NB16];
 #pragma unroll
@@ -244,6 +260,7 @@ __global__ void __launch_bounds__(NW * 64) linear_kernel(LinArgs a) {
             for (int r = 0; r < 4; r++)
                 red[(w * MR + mt * 16 + 4 * q + r) * NBP + nb * 16 + c] = acc[mt][nb][r];
     __syncthreads();
+    Q3_PH(3);  // partials in LDS, barrier passed
 
     // ---- 5. fixed-order sum over waves + epilogue ----
     if (EPI == EPI_STORE || EPI == EPI_RESID) {
@@ -262,7 +279,7 @@ __global__ void __launch_bounds__(NW * 64) linear_kernel(LinArgs a) {
                     if (ok) a.y[(size_t)m * a.ldy + ng] = v;
                 } else {
                     const float hn = ok ? hold[i] + v : 0.f;
-                    if (ok) a.h_out[(size_t)m * a.N + ng] = hn;
+                    if (ok) a.h_out[frag_idx(m, ng, a.N)] = hn;
                     float s = hn * hn;
                     s += __shfl_xor(s, 8, 16);
                     s += __shfl_xor(s, 4, 16);
@@ -289,7 +306,7 @@ __global__ void __launch_bounds__(NW * 64) linear_kernel(LinArgs a) {
                 const int m = m0 + mr;
                 if (m < a.M) {
                     const float sg = __fdividef(g, 1.0f + __expf(-g));   // hardware exp/rcp: ~1e-6 relative, far below the fp16 rounding that follows
-                    a.act[(size_t)m * (a.N / 2) + (size_t)(tile0 / NB16) * NH + j] = sat_half(sg * u);
+                    a.act[frag_idx(m, (tile0 / NB16) * NH + j, a.N / 2)] = sat_half(sg * u);
                 }
             }
         }
@@ -386,19 +403,20 @@ int launch_linear(hipStream_t s, const LinArgs& a, int pro, int epi) {
 // ---------------------------------------------------------------------------
 // ssq partials of uploaded rows
 // ---------------------------------------------------------------------------
-__global__ void ssq_rows_kernel(const float* __restrict__ h, float* __restrict__ ssq, int H) {
+__global__ void ssq_rows_kernel(const float* __restrict__ rows, float* __restrict__ h, float* __restrict__ ssq, int H) {
     const int r = blockIdx.x;
     for (int k4 = threadIdx.x; k4 < H / 4; k4 += blockDim.x) {
-        const float4 v = *(const float4*)(h + (size_t)r * H + k4 * 4);
+        const float4 v = *(const float4*)(rows + (size_t)r * H + k4 * 4);
+        *(float4*)(h + frag_idx(r, k4 * 4, H)) = v;
         float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
         s += __shfl_xor(s, 1, 4);
         s += __shfl_xor(s, 2, 4);
         if ((k4 & 3) == 0) ssq[(size_t)r * (H / 16) + (k4 >> 2)] = s;
     }
 }
-int launch_ssq_rows(hipStream_t s, const float* h, float* ssq, int R, int H) {
+int launch_ssq_rows(hipStream_t s, const float* rows, float* h, float* ssq, int R, int H) {
     if (R <= 0) return 0;
-    hipLaunchKernelGGL(ssq_rows_kernel, dim3(R), dim3(256), 0, s, h, ssq, H);
+    hipLaunchKernelGGL(ssq_rows_kernel, dim3(R), dim3(256), 0, s, rows, h, ssq, H);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
 }
@@ -410,7 +428,7 @@ __global__ void final_norm_kernel(FinalNormArgs a) {
     Q3_TL(40);
     __shared__ float inv_sh;
     const int r = a.row0 + blockIdx.x;
-    const int src = a.row_map ? a.row_map[r] : r;
+    const int src = a.row_map ? a.row_map[r] : r + a.src_off;
     if (threadIdx.x < 64) {
         float s = 0.f;
         for (int p = threadIdx.x; p < a.ssq_parts; p += 64) s += a.ssq[(size_t)src * a.ssq_parts + p];
@@ -420,7 +438,7 @@ __global__ void final_norm_kernel(FinalNormArgs a) {
     __syncthreads();
     const float iv = inv_sh;
     for (int k4 = threadIdx.x; k4 < a.H / 4; k4 += blockDim.x) {
-        const float4 v = *(const float4*)(a.h + (size_t)src * a.H + k4 * 4);
+        const float4 v = *(const float4*)(a.h + frag_idx(src, k4 * 4, a.H));
         const float4 g = *(const float4*)(a.gamma + k4 * 4);
         float4 o;
         o.x = (v.x * iv) * g.x;
@@ -429,14 +447,14 @@ __global__ void final_norm_kernel(FinalNormArgs a) {
         o.w = (v.w * iv) * g.w;
         if (a.out_f32) *(float4*)(a.out_f32 + (size_t)r * a.H + k4 * 4) = o;
         if (a.out_f16) {
-            half_t* p = a.out_f16 + (size_t)r * a.H + k4 * 4;
+            half_t* p = a.out_f16 + frag_idx(r, k4 * 4, a.H);
             p[0] = sat_half(o.x);
             p[1] = sat_half(o.y);
             p[2] = sat_half(o.z);
             p[3] = sat_half(o.w);
         }
         if (a.out_copy) {
-            *(float4*)(a.out_copy + (size_t)r * a.H + k4 * 4) = o;
+            *(float4*)(a.out_copy + frag_idx(r, k4 * 4, a.H)) = o;
             float s = o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
             s += __shfl_xor(s, 1, 4);
             s += __shfl_xor(s, 2, 4);
@@ -455,7 +473,7 @@ int launch_final_norm(hipStream_t s, const FinalNormArgs& a) {
 // embedding gather with ssq partials
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void store_row_ssq(float* h, float* ssq, int r, int H, int k4, float4 v) {
-    *(float4*)(h + (size_t)r * H + k4 * 4) = v;
+    *(float4*)(h + frag_idx(r, k4 * 4, H)) = v;
     float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     s += __shfl_xor(s, 1, 4);
     s += __shfl_xor(s, 2, 4);
@@ -698,7 +716,7 @@ __global__ void __launch_bounds__(1024) attn_kernel(AttnArgs a) {
             L += pl[i * 2 + hh] * c;
             o += pacc[(i * 2 + hh) * D + d] * c;
         }
-        a.out[(size_t)r * (a.n_heads * D) + (size_t)(2 * g + hh) * D + d] = sat_half(o / L);
+        a.out[frag_idx(r, (2 * g + hh) * D + d, a.n_heads * D)] = sat_half(o / L);
     }
 }
 
@@ -1073,10 +1091,14 @@ int launch_feedback(hipStream_t s, const int* codes16, int R, const float* talke
 #ifdef Q3_TIMELINE
 namespace q3 {
 // host control of the diagnostic timeline
+static unsigned long long* g_ph_host = nullptr;
 int tl_begin(unsigned cap) {
     unsigned long long* buf = nullptr;
     if (hipMalloc((void**)&buf, (size_t)cap * 16) != hipSuccess) return -1;
     hipMemset(buf, 0, (size_t)cap * 16);
+    if (hipMalloc((void**)&g_ph_host, (size_t)cap * 64) != hipSuccess) return -1;
+    hipMemset(g_ph_host, 0, (size_t)cap * 64);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_ph), &g_ph_host, sizeof(g_ph_host));
     unsigned zero = 0;
     hipMemcpyToSymbol(HIP_SYMBOL(g_tl_idx), &zero, 4);
     hipMemcpyToSymbol(HIP_SYMBOL(g_tl_cap), &cap, 4);
@@ -1101,4 +1123,7 @@ int tl_end(unsigned long long* out, unsigned cap) {
 extern "C" int q3t_set_skip(int on) { return hipMemcpyToSymbol(HIP_SYMBOL(q3::g_skip), &on, 4) == hipSuccess ? 0 : -1; }
 extern "C" int q3t_tl_begin(unsigned cap) { return q3::tl_begin(cap); }
 extern "C" int q3t_tl_end(unsigned long long* out, unsigned cap) { return q3::tl_end(out, cap); }
+extern "C" int q3t_tl_phases(unsigned long long* out, unsigned n) {
+    return hipMemcpy(out, q3::g_ph_host, (size_t)n * 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
 #endif

@@ -51,9 +51,15 @@ int kv_alloc(KVCache& kv, int n_layers, int n_slots, int n_kv, int n_ctx);
 void kv_free(KVCache& kv);
 
 // Activations of one stack pass over up to max_rows rows.
+// host mirror of frag_idx (q3_kernels.hip): position of element (m, k) of a [rows][K] GEMM-input matrix
+inline size_t frag_idx_host(int m, int k, int K) {
+    return ((((size_t)(m >> 4) * (K >> 5) + (k >> 5)) * 64 + (m & 15) + 16 * ((k >> 3) & 3)) << 3) + (k & 7);
+}
+
 struct Work {
-    int max_rows = 0, hidden = 0;
-    float *h = nullptr, *ssq = nullptr, *qkv = nullptr;
+    int max_rows = 0, hidden = 0;   // max_rows is padded to a multiple of 64 (largest row tile)
+    float* rows_in = nullptr;       // row-major staging of uploaded embedding rows
+    float *h = nullptr, *ssq = nullptr, *qkv = nullptr;   // h: fragment order
     half_t *attn = nullptr, *act = nullptr;
     float* hidden_f32 = nullptr;   // post-final-norm
     half_t* hidden_f16 = nullptr;

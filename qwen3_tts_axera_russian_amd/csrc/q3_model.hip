@@ -248,22 +248,28 @@ void kv_free(KVCache& kv) {
 }
 
 int work_alloc(Work& w, const ModelCfg& c, int max_rows, int ffn, int max_vocab) {
+    max_rows = (max_rows + 63) / 64 * 64;
     w.max_rows = max_rows;
     w.hidden = c.hidden;
     const size_t R = (size_t)max_rows;
     const int qkv_ld = (c.n_heads + 2 * c.n_kv) * c.head_dim;
+    Q3_HIP(hipMalloc((void**)&w.rows_in, R * c.hidden * 4), -1);
     Q3_HIP(hipMalloc((void**)&w.h, R * c.hidden * 4), -1);
+    Q3_HIP(hipMemset(w.h, 0, R * c.hidden * 4), -1);
     Q3_HIP(hipMalloc((void**)&w.ssq, R * (c.hidden / 16) * 4), -1);
     Q3_HIP(hipMalloc((void**)&w.qkv, R * qkv_ld * 4), -1);
     Q3_HIP(hipMalloc((void**)&w.attn, R * c.n_heads * c.head_dim * 2), -1);
+    Q3_HIP(hipMemset(w.attn, 0, R * c.n_heads * c.head_dim * 2), -1);
     Q3_HIP(hipMalloc((void**)&w.act, R * ffn * 2), -1);
+    Q3_HIP(hipMemset(w.act, 0, R * ffn * 2), -1);
     Q3_HIP(hipMalloc((void**)&w.hidden_f32, R * c.hidden * 4), -1);
     Q3_HIP(hipMalloc((void**)&w.hidden_f16, R * c.hidden * 2), -1);
+    Q3_HIP(hipMemset(w.hidden_f16, 0, R * c.hidden * 2), -1);
     Q3_HIP(hipMalloc((void**)&w.logits, R * max_vocab * 4), -1);
     return 0;
 }
 void work_free(Work& w) {
-    void* ps[] = {w.h, w.ssq, w.qkv, w.attn, w.act, w.hidden_f32, w.hidden_f16, w.logits};
+    void* ps[] = {w.rows_in, w.h, w.ssq, w.qkv, w.attn, w.act, w.hidden_f32, w.hidden_f16, w.logits};
     for (void* p : ps)
         if (p) hipFree(p);
     w = Work();
@@ -274,6 +280,10 @@ int run_stack(hipStream_t s, const Model& m, const DevStack& st, Work& w, KVCach
     const ModelCfg& c = m.cfg;
     const int H = c.hidden, D = c.head_dim;
     const int qkv_ld = (c.n_heads + 2 * c.n_kv) * D;
+    if (row0 % 16) {
+        Q3_LOG("run_stack: row0=%d must be a multiple of 16 (fragment-ordered activations)", row0);
+        return -1;
+    }
     if (row0 + R > w.max_rows) {
         Q3_LOG("run_stack: %d rows > workspace %d", R, w.max_rows);
         return -1;

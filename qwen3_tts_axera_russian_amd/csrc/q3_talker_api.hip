@@ -32,7 +32,7 @@ int attn_threads_for(int n_ctx) { return n_ctx <= 64 ? 256 : 1024; }
 // rows already in w.h (f32) -> hidden of `out_rows` rows (row_map on device or null = identity)
 int forward_rows(TalkerCtx* c, int R, const RowMap& rm) {
     const Model& m = *c->tm->m;
-    if (launch_ssq_rows(c->s, c->w.h, c->w.ssq, R, m.cfg.hidden)) return -1;
+    if (launch_ssq_rows(c->s, c->w.rows_in, c->w.h, c->w.ssq, R, m.cfg.hidden)) return -1;
     if (run_stack(c->s, m, m.talker, c->w, c->kv, R, rm, attn_threads_for(c->n_ctx))) return -1;
     return 0;
 }
@@ -41,8 +41,9 @@ int final_hidden(TalkerCtx* c, int first_row, int R) {
     const Model& m = *c->tm->m;
     const int H = m.cfg.hidden;
     FinalNormArgs f;
-    f.h = c->w.h + (size_t)first_row * H;
-    f.ssq = c->w.ssq + (size_t)first_row * (H / 16);
+    f.h = c->w.h;
+    f.ssq = c->w.ssq;
+    f.src_off = first_row;
     f.ssq_parts = H / 16;
     f.gamma = m.talker.final_norm;
     f.eps = m.cfg.eps;
@@ -166,7 +167,7 @@ int wrapper_decode_embd_slot(void* ctx, int slot, const float* embd, int n_token
                n_tokens, n_embd, pos_start, slot, c->n_ctx, c->n_batch);
         return -1;
     }
-    Q3_HIP(hipMemcpyAsync(c->w.h, embd, sizeof(float) * (size_t)n_tokens * H, hipMemcpyHostToDevice, c->s), -1);
+    Q3_HIP(hipMemcpyAsync(c->w.rows_in, embd, sizeof(float) * (size_t)n_tokens * H, hipMemcpyHostToDevice, c->s), -1);
     if (n_tokens == 1) {
         // decode step: one captured graph, (slot,pos) read from device arrays
         c->i_pinned[0] = slot;  // the previous call synchronised the stream: the buffer is free
@@ -227,7 +228,7 @@ int wrapper_decode_embd_batch(void* ctx, const float* embd, int n_rows, int n_em
         for (int q = 0; q < r; q++)
             if (slot_ids[q] == slot_ids[r]) return -1;  // rows must hit distinct sequences
     }
-    Q3_HIP(hipMemcpyAsync(c->w.h, embd, sizeof(float) * (size_t)n_rows * H, hipMemcpyHostToDevice, c->s), -1);
+    Q3_HIP(hipMemcpyAsync(c->w.rows_in, embd, sizeof(float) * (size_t)n_rows * H, hipMemcpyHostToDevice, c->s), -1);
     Q3_HIP(hipMemcpyAsync(c->d_slot, slot_ids, sizeof(int) * n_rows, hipMemcpyHostToDevice, c->s), -1);
     Q3_HIP(hipMemcpyAsync(c->d_pos, pos, sizeof(int) * n_rows, hipMemcpyHostToDevice, c->s), -1);
     RowMap rm;
@@ -247,8 +248,9 @@ int wrapper_codec_head(void* ctx, const float* hidden, int n_rows, float* logits
     if (!c || !hidden || !logits_out || n_rows <= 0 || n_rows > c->n_batch) return -1;
     const Model& m = *c->tm->m;
     const int H = m.cfg.hidden, V = m.cfg.talker_vocab;
-    std::vector<uint16_t> h16((size_t)n_rows * H);
-    for (size_t i = 0; i < h16.size(); i++) h16[i] = f2h_sat(hidden[i]);
+    std::vector<uint16_t> h16((size_t)((n_rows + 15) / 16 * 16) * H, 0);
+    for (int r = 0; r < n_rows; r++)
+        for (int k = 0; k < H; k++) h16[frag_idx_host(r, k, H)] = f2h_sat(hidden[(size_t)r * H + k]);
     Q3_HIP(hipMemcpyAsync(c->w.hidden_f16, h16.data(), h16.size() * 2, hipMemcpyHostToDevice, c->s), -1);
     LinArgs a;
     a.wp = m.talker_head.wp;

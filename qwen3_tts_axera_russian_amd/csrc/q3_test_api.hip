@@ -41,7 +41,8 @@ int q3t_linear(int M, int N, int K, const uint16_t* W, int gateup, int pro, int 
                const float* h, const float* gamma, float eps, float* y_or_h_io, float* ssq_out, uint16_t* act_out,
                int nt) {
     hipStream_t s = nullptr;
-    DBuf dW, dWp, dx, dh, dssq, dg, dy, dso, dact;
+    const int Mp = (M + 63) / 64 * 64;  // buffers padded to the largest row tile
+    DBuf dW, dWp, dx, dhrows, dh, dssq, dg, dy, dso, dact;
     if (!dW.up(W, (size_t)N * K * 2) || !dWp.alloc((size_t)N * K * 2)) return -1;
     if (gateup) {
         if (launch_pack_linear(s, (const half_t*)dW.p, N / 2, K, (half_t*)dWp.p, 0, 2)) return -1;
@@ -56,35 +57,54 @@ int q3t_linear(int M, int N, int K, const uint16_t* W, int gateup, int pro, int 
     a.M = M;
     a.nt = nt;
     if (pro == PRO_F16) {
-        if (!dx.up(x16, (size_t)M * K * 2)) return -1;
+        std::vector<uint16_t> xp((size_t)Mp * K, 0);   // host rows -> fragment order
+        for (int m = 0; m < M; m++)
+            for (int k = 0; k < K; k++) xp[frag_idx_host(m, k, K)] = x16[(size_t)m * K + k];
+        if (!dx.up(xp.data(), xp.size() * 2)) return -1;
         a.x16 = (const half_t*)dx.p;
     } else {
-        if (!dh.up(h, (size_t)M * K * 4) || !dssq.alloc((size_t)M * (K / 16) * 4) || !dg.up(gamma, (size_t)K * 4)) return -1;
-        if (launch_ssq_rows(s, (const float*)dh.p, (float*)dssq.p, M, K)) return -1;
+        if (!dhrows.up(h, (size_t)M * K * 4) || !dh.alloc((size_t)Mp * K * 4) || !dssq.alloc((size_t)Mp * (K / 16) * 4) ||
+            !dg.up(gamma, (size_t)K * 4))
+            return -1;
+        hipMemset(dh.p, 0, (size_t)Mp * K * 4);
+        if (launch_ssq_rows(s, (const float*)dhrows.p, (float*)dh.p, (float*)dssq.p, M, K)) return -1;
         a.h = (const float*)dh.p;
         a.ssq = (const float*)dssq.p;
         a.ssq_parts = K / 16;
         a.gamma = (const float*)dg.p;
         a.eps = eps;
     }
+    std::vector<float> hp;
     if (epi == EPI_STORE) {
         if (!dy.alloc((size_t)M * N * 4)) return -1;
         a.y = (float*)dy.p;
         a.ldy = N;
     } else if (epi == EPI_RESID) {
-        if (!dy.up(y_or_h_io, (size_t)M * N * 4) || !dso.alloc((size_t)M * (N / 16) * 4)) return -1;
+        hp.assign((size_t)Mp * N, 0.f);
+        for (int m = 0; m < M; m++)
+            for (int n = 0; n < N; n++) hp[frag_idx_host(m, n, N)] = y_or_h_io[(size_t)m * N + n];
+        if (!dy.up(hp.data(), hp.size() * 4) || !dso.alloc((size_t)Mp * (N / 16) * 4)) return -1;
         a.h_out = (float*)dy.p;
         a.ssq_out = (float*)dso.p;
     } else {
-        if (!dact.alloc((size_t)M * (N / 2) * 2)) return -1;
+        if (!dact.alloc((size_t)Mp * (N / 2) * 2)) return -1;
         a.act = (half_t*)dact.p;
     }
     if (launch_linear(s, a, pro, epi)) return -1;
     Q3_HIP(hipDeviceSynchronize(), -1);
-    if (epi == EPI_STORE || epi == EPI_RESID)
-        Q3_HIP(hipMemcpy(y_or_h_io, dy.p, (size_t)M * N * 4, hipMemcpyDeviceToHost), -1);
-    if (epi == EPI_RESID && ssq_out) Q3_HIP(hipMemcpy(ssq_out, dso.p, (size_t)M * (N / 16) * 4, hipMemcpyDeviceToHost), -1);
-    if (epi == EPI_SWIGLU) Q3_HIP(hipMemcpy(act_out, dact.p, (size_t)M * (N / 2) * 2, hipMemcpyDeviceToHost), -1);
+    if (epi == EPI_STORE) Q3_HIP(hipMemcpy(y_or_h_io, dy.p, (size_t)M * N * 4, hipMemcpyDeviceToHost), -1);
+    if (epi == EPI_RESID) {
+        Q3_HIP(hipMemcpy(hp.data(), dy.p, hp.size() * 4, hipMemcpyDeviceToHost), -1);
+        for (int m = 0; m < M; m++)
+            for (int n = 0; n < N; n++) y_or_h_io[(size_t)m * N + n] = hp[frag_idx_host(m, n, N)];
+        if (ssq_out) Q3_HIP(hipMemcpy(ssq_out, dso.p, (size_t)M * (N / 16) * 4, hipMemcpyDeviceToHost), -1);
+    }
+    if (epi == EPI_SWIGLU) {
+        std::vector<uint16_t> ap((size_t)Mp * (N / 2));
+        Q3_HIP(hipMemcpy(ap.data(), dact.p, ap.size() * 2, hipMemcpyDeviceToHost), -1);
+        for (int m = 0; m < M; m++)
+            for (int j = 0; j < N / 2; j++) act_out[(size_t)m * (N / 2) + j] = ap[frag_idx_host(m, j, N / 2)];
+    }
     return 0;
 }
 
@@ -94,6 +114,8 @@ float q3t_bench_linear(int M, int N, int K, int pro, int epi, int nt, int n_copi
     hipStream_t s = nullptr;
     if (hipStreamCreate(&s) != hipSuccess) return -1.f;
     const size_t wbytes = (size_t)N * K * 2;
+    const int Mreal = M;
+    M = (M + 63) / 64 * 64;  // allocation padding; the launch uses Mreal rows
     DBuf dW, dx, dh, dssq, dg, dy, dso, dact;
     if (!dW.alloc(wbytes * n_copies)) return -1.f;
     hipMemset(dW.p, 0x11, wbytes * n_copies);
@@ -111,7 +133,7 @@ float q3t_bench_linear(int M, int N, int K, int pro, int epi, int nt, int n_copi
     LinArgs a;
     a.N = N;
     a.K = K;
-    a.M = M;
+    a.M = Mreal;
     a.nt = nt;
     a.x16 = (const half_t*)dx.p;
     a.h = (const float*)dh.p;

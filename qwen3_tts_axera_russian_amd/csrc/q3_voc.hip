@@ -28,7 +28,8 @@ enum { VF_SNAKE = 1, VF_RES_ADD = 2, VF_RES_SAVE = 4, VF_CLAMP = 8 };
 struct ConvArgs {
     const float* x = nullptr;   // [B][Cin][Lin]
     float* y = nullptr;         // [B][Cout][Lin*stride]
-    const float* wk = nullptr;  // [K][M][Cin], M = Cout*stride virtual rows
+    const float* wk = nullptr;  // [Cin/8][K][8][Mp]: rows contiguous (Mp = M rounded up to 4), M = Cout*stride virtual rows
+    int Mp = 0;
     const float* bias = nullptr;
     const float* alpha = nullptr;     // [Cin] Snake: x + inv_beta * sin^2(alpha x), applied to the input
     const float* inv_beta = nullptr;
@@ -65,17 +66,17 @@ __global__ void __launch_bounds__(256) conv_kernel(ConvArgs a) {
             for (int i = 0; i < 16; i++) acc[mt][i] = 0.f;
         for (int ci0 = 0; ci0 < a.Cin; ci0 += KC) {
             __syncthreads();  // previous stage (or tile) fully consumed
-            // stage the weights of all taps for KC channels: global [k][m][ci] -> Ws[k][ci][m]
-            for (int idx = tid; idx < KT * TM * Q; idx += 256) {
-                const int qq = idx % Q, mm = (idx / Q) % TM, k = idx / (Q * TM);
-                const int m = m0 + mm;
+            // stage the weights of all taps for KC channels.  Packed layout [ci/8][k][ci%8][Mp] (rows contiguous):
+            // a tile row is TM contiguous floats, copied with 16-B loads / ds_write_b128, no transposition
+            for (int idx = tid; idx < KT * KC * (TM / 4); idx += 256) {
+                const int m4 = idx % (TM / 4), ci = (idx / (TM / 4)) % KC, k = idx / ((TM / 4) * KC);
+                const int m = m0 + m4 * 4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m < a.M) v = *(const float4*)(a.wk + ((size_t)k * a.M + m) * a.Cin + ci0 + qq * 4);
-                float* d = Ws + (k * KC + qq * 4) * TMP + mm;
-                d[0] = v.x;
-                d[TMP] = v.y;
-                d[2 * TMP] = v.z;
-                d[3 * TMP] = v.w;
+                if (m < a.Mp) {
+                    const int cg = ci0 + ci;
+                    v = *(const float4*)(a.wk + ((((size_t)(cg >> 3) * KT + k) * 8 + (cg & 7)) * a.Mp + m));
+                }
+                *(float4*)(Ws + (k * KC + ci) * TMP + m4 * 4) = v;
             }
             // the input line buffer (causal: columns left of 0 are zero; Snake(0) = 0 so padding commutes)
             for (int idx = tid; idx < KC * XW; idx += 256) {
@@ -141,6 +142,7 @@ static int launch_conv_t(hipStream_t s, const ConvArgs& a, int B) {
     }
     const size_t lds = ((size_t)KT * KC * TMP + (size_t)KC * (VTN + halo)) * sizeof(float);
     ConvArgs c = a;
+    c.Mp = (a.M + 3) / 4 * 4;
     c.tiles_l = (a.Lin + VTN - 1) / VTN;
     c.tiles_m = (a.M + TM - 1) / TM;
     c.n_tiles = c.tiles_l * c.tiles_m * B;
@@ -399,6 +401,18 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
                                 wk[((size_t)(J - 1 - j) * op.cout * s + (size_t)co * s + ph) * op.cin + ci] =
                                     src[((size_t)ci * op.cout + co) * op.k + ph + j * s];
             }
+            {   // [tap][row][cin] -> stage-major [cin/8][tap][cin%8][Mp]
+                const int KTAPS = op.op == VOP_CONV ? op.k : op.k / op.p0;
+                const int Mrows = op.op == VOP_CONV ? op.cout : op.cout * op.p0;
+                const int Mp = (Mrows + 3) / 4 * 4;
+                std::vector<float> wp((size_t)(op.cin / 8) * KTAPS * 8 * Mp, 0.f);
+                for (int k = 0; k < KTAPS; k++)
+                    for (int m = 0; m < Mrows; m++)
+                        for (int ci = 0; ci < op.cin; ci++)
+                            wp[((((size_t)(ci >> 3) * KTAPS + k) * 8 + (ci & 7)) * Mp) + m] =
+                                wk[((size_t)k * Mrows + m) * op.cin + ci];
+                wk.swap(wp);
+            }
             op.w = voc_up_host(v, wk);
             op.bias = bs ? voc_up(v, bs) : nullptr;
             if (op.flags & VF_SNAKE) {
@@ -414,6 +428,11 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
                 }
                 op.alpha = voc_up_host(v, ha);
                 op.inv_beta = voc_up_host(v, hb);
+            }
+            if (op.cin % 8) {
+                Q3_LOG("vocoder op %d: Cin=%d is not a multiple of 8", i, op.cin);
+                ok = false;
+                break;
             }
             ok = ok && op.w;
             flops += 2.0 * op.cin * op.cout * op.k * L;  // per input column; convT: k taps spread over s outputs
@@ -458,7 +477,8 @@ int voc_samples_per_token(void* vv) { return vv ? ((Voc*)vv)->upsample : 0; }
 float voc_last_decode_ms(void* vv) { return vv ? ((Voc*)vv)->last_ms : -1.f; }
 double voc_decode_flops(void* vv, int B) { return vv ? ((Voc*)vv)->flops_per_chunk * B : 0.0; }
 
-static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = nullptr, long* outL = nullptr) {
+static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = nullptr, long* outL = nullptr,
+                   float* op_ms = nullptr) {
     // ping-pong between buf[0]/buf[1]; buf[2] keeps the residual-unit input
     int cur = 0;
     int C = 0;
@@ -467,6 +487,7 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
     const size_t nrun = n_ops < 0 ? v->ops.size() : (size_t)n_ops < v->ops.size() ? (size_t)n_ops : v->ops.size();
     for (size_t i = 0; i < nrun; i++) {
         const VocOp& op = v->ops[i];
+        if (op_ms) hipEventRecord(v->e0, v->s);
         float* in = v->buf[cur];
         float* out = v->buf[cur ^ 1];
         if (op.op == VOP_RVQ) {
@@ -508,6 +529,11 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
             if (op.op == VOP_CONVT) L *= op.p0;
         }
         cur ^= 1;
+        if (op_ms) {
+            hipEventRecord(v->e1, v->s);
+            hipStreamSynchronize(v->s);
+            hipEventElapsedTime(&op_ms[i], v->e0, v->e1);
+        }
     }
     *out_dev = v->buf[cur];
     if (outC) *outC = C;
@@ -527,6 +553,15 @@ int voc_decode(void* vv, const int64_t* codes, int B, float* out) {
     Q3_HIP(hipStreamSynchronize(v->s), -1);
     hipEventElapsedTime(&v->last_ms, v->e0, v->e1);
     return 0;
+}
+
+// test hook: per-op GPU milliseconds of one decode of B chunks (codes already uploaded by a previous voc_decode)
+int voc_debug_profile(void* vv, int B, float* op_ms, int max_ops) {
+    Voc* v = (Voc*)vv;
+    if (!v || B <= 0 || B > v->max_batch || (int)v->ops.size() > max_ops) return -1;
+    float* res = nullptr;
+    if (voc_run(v, B, &res, -1, nullptr, nullptr, op_ms)) return -1;
+    return (int)v->ops.size();
 }
 
 // test hook: run only the first n_ops ops, return the activation [B][C][L]
