@@ -20,6 +20,8 @@ LIB = os.path.join(HERE, "lib")
 SOURCES = ["q3_common.cpp", "q3_kernels.hip", "q3_model.hip", "q3_talker_api.hip", "q3_cp_api.hip",
            "q3_engine.hip", "q3_voc.hip", "q3_test_api.hip"]
 ARCH = os.environ.get("Q3_OFFLOAD_ARCH", "gfx950")
+# kernarg preload: the leading scalar kernel arguments arrive in SGPRs at wave launch (gfx940+)
+EXTRA = os.environ.get("Q3_EXTRA_HIPCC_FLAGS", "-mllvm -amdgpu-kernarg-preload-count=16").split()
 
 
 def _newer(dst: str, srcs) -> bool:
@@ -45,7 +47,7 @@ def build(force: bool = False, verbose: bool = False, timeline: bool = False) ->
         if not force and _newer(o, [s] + hdrs):
             continue
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", s, "-o", o,
-               "-Wno-unused-result", "-Wno-unused-value", "-Wno-pass-failed"] + (["-DQ3_TIMELINE"] if timeline else [])
+               "-Wno-unused-result", "-Wno-unused-value", "-Wno-pass-failed"] + (["-DQ3_TIMELINE"] if timeline else []) + EXTRA
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

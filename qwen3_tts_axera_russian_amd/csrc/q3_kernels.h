@@ -14,6 +14,7 @@ enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2 };
 
 // y[M][N] = A[M][K] . W[N][K]^T with W in MFMA-fragment order (see pack_linear).
 struct LinArgs {
+    int tl_node = -1;  // diagnostic timeline build only: graph node index
     const half_t* wp = nullptr;  // packed weights
     int N = 0, K = 0, M = 0;   // rows [m_begin, M) are computed
     int m_begin = 0;
@@ -46,6 +47,7 @@ int launch_pack_linear(hipStream_t s, const half_t* src, int N, int K, half_t* d
 
 enum { ATTN_FUSED = 0, ATTN_PREP = 1, ATTN_ATTEND = 2 };
 struct AttnArgs {
+    int tl_node = -1;  // diagnostic timeline build only: graph node index
     float* qkv = nullptr;  // [R][ld]: q heads, then k heads, then v heads (raw projections)
     int ld = 0, R = 0, row0 = 0;   // rows row0 .. row0+R-1
     const float* q_norm = nullptr;
@@ -72,6 +74,7 @@ int launch_ssq_rows(hipStream_t s, const float* rows, float* h, float* ssq, int 
 // hidden = (h*inv)*gamma per row; optional outputs: f32 hidden, fp16 hidden,
 // a second f32 copy (+ its ssq partials) that seeds the code predictor.
 struct FinalNormArgs {
+    int tl_node = -1;  // diagnostic timeline build only: graph node index
     const float* h = nullptr;
     const float* ssq = nullptr;
     int ssq_parts = 0;
@@ -96,6 +99,7 @@ int launch_gather_embed(hipStream_t s, const float* table, int V, int H, const i
 
 // Talker sampling (llamacpp_talker_server.py:163-206, greedy form).
 struct TalkerSampleArgs {
+    int tl_node = -1;  // diagnostic timeline build only: graph node index
     const float* logits = nullptr;  // [R][V]
     int V = 0, R = 0, row0 = 0, R_total = 0;   // rows row0..row0+R-1 of a batch of R_total (0 = R)
     int audio_vocab = 2048, eos = 2150;
@@ -123,6 +127,7 @@ int launch_talker_sample(hipStream_t s, const TalkerSampleArgs& a);
 // Code-predictor group argmax (+ next embedding gather, or the feedback sum
 // of tts_client.py:199-208 after the last group).
 struct CpArgmaxArgs {
+    int tl_node = -1;  // diagnostic timeline build only: graph node index
     const float* logits = nullptr;  // [R][V]
     int V = 0, R = 0, H = 0, row0 = 0, R_total = 0;
     int group = 0;                 // writes column group+1 of the row's current frame
@@ -148,5 +153,8 @@ int launch_cp_argmax(hipStream_t s, const CpArgmaxArgs& a);
 int launch_feedback(hipStream_t s, const int* codes16, int R, const float* talker_emb, int talker_vocab,
                     const float* const* cp_tables, int cp_vocab, int n_groups, const float* pad_embed,
                     float* h_out, float* ssq_out, int H);
+
+// diagnostic timeline build: node numbering of the launches that follow (no-op otherwise)
+int tl_next_node();
 
 }  // namespace q3

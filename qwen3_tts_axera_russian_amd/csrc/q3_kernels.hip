@@ -40,8 +40,25 @@ struct TlScope {
         if (slot < g_tl_cap) g_tl[2 * slot + 1] = wall_clock64();
     }
 };
+__device__ unsigned long long* g_tl2 = nullptr;  // [nodes][TL2_MAXB][2] per-block start/end stamps
+constexpr int TL2_MAXB = 1024;
+struct TlScope2 {
+    unsigned long long t0;
+    int node;
+    __device__ __forceinline__ TlScope2(int n) : node(n) { t0 = wall_clock64(); }
+    __device__ __forceinline__ ~TlScope2() {
+        if (g_tl2 && node >= 0 && threadIdx.x == 0) {
+            const unsigned b = blockIdx.x + gridDim.x * blockIdx.y;
+            if (b < TL2_MAXB) {
+                g_tl2[((size_t)node * TL2_MAXB + b) * 2] = t0;
+                g_tl2[((size_t)node * TL2_MAXB + b) * 2 + 1] = wall_clock64();
+            }
+        }
+    }
+};
 #define Q3_TL(id)      \
     if (g_skip) return; \
+    TlScope2 tl_scope2_(a.tl_node); \
     TlScope tl_scope_(id)
 #define Q3_PH(n)                                                                                       \
     do {                                                                                               \
@@ -121,8 +138,26 @@ int launch_pack_linear(hipStream_t s, const half_t* src, int N, int K, half_t* d
 //   come from L2, partial tiles are summed across waves through LDS in a fixed
 //   order (deterministic), then the epilogue runs on the summed tile.
 // ---------------------------------------------------------------------------
+// The first arguments are the ones the load addresses need: with -amdgpu-kernarg-preload-count=16 they
+// arrive in SGPRs at wave launch instead of behind two dependent scalar-memory round trips.
 template <int NB16, int MT16, int KBW, int NW, int PRO, int EPI, bool NT>
-__global__ void __launch_bounds__(NW * 64) linear_kernel(LinArgs a) {
+__global__ void __launch_bounds__(NW * 64)
+    linear_kernel(const half_t* __restrict__ p_wp, const void* __restrict__ p_asrc, const float* __restrict__ p_ssq,
+                  const float* __restrict__ p_gamma, void* __restrict__ p_out, int p_M, int p_N, int p_m_begin,
+                  int p_swap, float p_eps, LinArgs a) {
+    a.wp = p_wp;
+    a.x16 = (const half_t*)p_asrc;
+    a.h = (const float*)p_asrc;
+    a.ssq = p_ssq;
+    a.gamma = p_gamma;
+    a.y = (float*)p_out;
+    a.h_out = (float*)p_out;
+    a.act = (half_t*)p_out;
+    a.M = p_M;
+    a.N = p_N;
+    a.m_begin = p_m_begin;
+    a.swap_grid = p_swap;
+    a.eps = p_eps;
     constexpr int MR = MT16 * 16, NB = NB16 * 16, NBP = NB + 4, KB = NW * KBW, K = KB * 32;
     constexpr int NTH = NW * 64;
     constexpr int NOUT = (EPI == EPI_SWIGLU) ? MR * NB / 2 : MR * NB;   // outputs of this workgroup
@@ -251,6 +286,8 @@ __global__ void __launch_bounds__(NW * 64) linear_kernel(LinArgs a) {
             for (int nb = 0; nb < NB16; nb++)
                 acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][kbi], wf[nb][kbi], acc[mt][nb], 0, 0, 0);
 
+    asm volatile("" ::"v"(acc[0][0][0]));  // (diagnostic stamp below must not float above the MFMAs)
+    Q3_PH(2);  // MFMAs done (weights landed)
     // ---- 4. partial tiles -> LDS.  D layout: col = lane&15, row = 4*(lane>>4) + reg. ----
 #pragma unroll
     for (int mt = 0; mt < MT16; mt++)
@@ -325,10 +362,14 @@ static int launch_linear_nt(hipStream_t s, const LinArgs& a) {
         attr_set = true;
     }
     LinArgs b = a;
+    b.tl_node = tl_next_node();
     const unsigned nt_ = a.N / (16 * NB16), nr_ = (a.M - a.m_begin + MR - 1) / MR;
     b.swap_grid = nr_ > 2 ? 1 : 0;
     dim3 grid(b.swap_grid ? nr_ : nt_, b.swap_grid ? nt_ : nr_);
-    hipLaunchKernelGGL((linear_kernel<NB16, MT16, KBW, NW, PRO, EPI, NT>), grid, dim3(NW * 64), lds, s, b);
+    const void* asrc = PRO == PRO_F16 ? (const void*)b.x16 : (const void*)b.h;
+    void* outp = EPI == EPI_STORE ? (void*)b.y : EPI == EPI_RESID ? (void*)b.h_out : (void*)b.act;
+    hipLaunchKernelGGL((linear_kernel<NB16, MT16, KBW, NW, PRO, EPI, NT>), grid, dim3(NW * 64), lds, s, b.wp, asrc, b.ssq,
+                       b.gamma, outp, b.M, b.N, b.m_begin, b.swap_grid, b.eps, b);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
 }
@@ -464,7 +505,9 @@ __global__ void final_norm_kernel(FinalNormArgs a) {
 }
 int launch_final_norm(hipStream_t s, const FinalNormArgs& a) {
     if (a.R <= 0) return 0;
-    hipLaunchKernelGGL(final_norm_kernel, dim3(a.R), dim3(256), 0, s, a);
+    FinalNormArgs a2 = a;
+    a2.tl_node = tl_next_node();
+    hipLaunchKernelGGL(final_norm_kernel, dim3(a.R), dim3(256), 0, s, a2);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
 }
@@ -483,7 +526,6 @@ __device__ __forceinline__ void store_row_ssq(float* h, float* ssq, int r, int H
 __global__ void gather_embed_kernel(const float* __restrict__ table, int V, int H, const int* __restrict__ tok,
                                     int tok_stride, const int* __restrict__ n_frames, int frame_cap, int col,
                                     float* __restrict__ h, float* __restrict__ ssq, int row0, int R_total) {
-    Q3_TL(41);
     const int r = row0 + blockIdx.x;
     int t;
     if (n_frames) {
@@ -733,11 +775,13 @@ int launch_attn(hipStream_t s, const AttnArgs& a, int mode) {
     if (threads < 256) threads = 256;
     if (threads > 1024) threads = 1024;
     const size_t lds = ((size_t)(threads / 64) * (4 + 2 * 128)) * sizeof(float);
+    AttnArgs a2 = a;
+    a2.tl_node = tl_next_node();
     dim3 grid(a.R, a.n_kv);
 #define Q3_ATTN(MODE_)                                                                                   \
     {                                                                                                    \
         hipLaunchKernelGGL((attn_kernel<MODE_>), grid, dim3(mode == ATTN_PREP ? 256 : threads),          \
-                           mode == ATTN_PREP ? 0 : lds, s, a);                                           \
+                           mode == ATTN_PREP ? 0 : lds, s, a2);                                          \
     }
     if (mode == ATTN_FUSED) Q3_ATTN(ATTN_FUSED)
     else if (mode == ATTN_PREP) Q3_ATTN(ATTN_PREP)
@@ -937,7 +981,9 @@ __global__ void talker_sample_kernel(TalkerSampleArgs a) {
 int launch_talker_sample(hipStream_t s, const TalkerSampleArgs& a) {
     if (a.R <= 0) return 0;
     const size_t lds = a.temperature > 1e-6f ? (size_t)a.V * sizeof(float) : 0;
-    hipLaunchKernelGGL(talker_sample_kernel, dim3(a.R), dim3(256), lds, s, a);
+    TalkerSampleArgs a2 = a;
+    a2.tl_node = tl_next_node();
+    hipLaunchKernelGGL(talker_sample_kernel, dim3(a.R), dim3(256), lds, s, a2);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
 }
@@ -1065,7 +1111,9 @@ __global__ void __launch_bounds__(256) cp_argmax_kernel(CpArgmaxArgs a) {
 int launch_cp_argmax(hipStream_t s, const CpArgmaxArgs& a) {
     if (a.R <= 0) return 0;
     const size_t lds = a.temperature > 1e-6f ? (size_t)a.V * sizeof(float) : 0;
-    hipLaunchKernelGGL(cp_argmax_kernel, dim3(a.R), dim3(256), lds, s, a);
+    CpArgmaxArgs a2 = a;
+    a2.tl_node = tl_next_node();
+    hipLaunchKernelGGL(cp_argmax_kernel, dim3(a.R), dim3(256), lds, s, a2);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
 }
@@ -1088,10 +1136,32 @@ int launch_feedback(hipStream_t s, const int* codes16, int R, const float* talke
 
 }  // namespace q3
 
+#ifndef Q3_TIMELINE
+namespace q3 {
+int tl_next_node() { return -1; }
+}
+#endif
 #ifdef Q3_TIMELINE
 namespace q3 {
 // host control of the diagnostic timeline
 static unsigned long long* g_ph_host = nullptr;
+static unsigned long long* g_tl2_host = nullptr;
+static int g_tl_node_counter = -1;  // -1: numbering off
+int tl_next_node() { return g_tl_node_counter < 0 ? -1 : g_tl_node_counter++; }
+int tl2_begin(int max_nodes) {
+    if (hipMalloc((void**)&g_tl2_host, (size_t)max_nodes * TL2_MAXB * 16) != hipSuccess) return -1;
+    hipMemset(g_tl2_host, 0, (size_t)max_nodes * TL2_MAXB * 16);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_tl2), &g_tl2_host, sizeof(g_tl2_host));
+    g_tl_node_counter = 0;
+    return 0;
+}
+int tl2_end(unsigned long long* out, int max_nodes) {
+    hipDeviceSynchronize();
+    const int n = g_tl_node_counter;
+    g_tl_node_counter = -1;
+    hipMemcpy(out, g_tl2_host, (size_t)(n < max_nodes ? n : max_nodes) * TL2_MAXB * 16, hipMemcpyDeviceToHost);
+    return n;
+}
 int tl_begin(unsigned cap) {
     unsigned long long* buf = nullptr;
     if (hipMalloc((void**)&buf, (size_t)cap * 16) != hipSuccess) return -1;
@@ -1123,6 +1193,8 @@ int tl_end(unsigned long long* out, unsigned cap) {
 extern "C" int q3t_set_skip(int on) { return hipMemcpyToSymbol(HIP_SYMBOL(q3::g_skip), &on, 4) == hipSuccess ? 0 : -1; }
 extern "C" int q3t_tl_begin(unsigned cap) { return q3::tl_begin(cap); }
 extern "C" int q3t_tl_end(unsigned long long* out, unsigned cap) { return q3::tl_end(out, cap); }
+extern "C" int q3t_tl2_begin(int max_nodes) { return q3::tl2_begin(max_nodes); }
+extern "C" int q3t_tl2_end(unsigned long long* out, int max_nodes) { return q3::tl2_end(out, max_nodes); }
 extern "C" int q3t_tl_phases(unsigned long long* out, unsigned n) {
     return hipMemcpy(out, q3::g_ph_host, (size_t)n * 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }

@@ -314,3 +314,62 @@ extern "C" float q3t_bench_multistream(int n_streams, int blocks, int threads, i
     }
     return (float)(std::chrono::duration<double, std::micro>(t1 - t0).count() / iters);
 }
+
+// ---- does a kernel's resource footprint change the per-node dispatch cost? ----
+namespace {
+__global__ void __launch_bounds__(256) chain_fat_vgpr_kernel(float* buf) {
+    // touches a high VGPR so the descriptor allocates ~256 registers per lane
+    asm volatile("v_mov_b32 v250, 0" ::: "v250");
+    (void)buf;
+}
+struct BigArgs {
+    float* p[20];
+    int v[16];
+};
+__global__ void chain_bigargs_kernel(BigArgs a) { (void)a; }
+}  // namespace
+
+// variant 0: empty, 1: 256-VGPR descriptor, 2: 80 KB dynamic LDS, 3: 224-byte kernarg
+extern "C" float q3t_bench_chain_footprint(int variant, int blocks, int threads, int n_kernels, int iters) {
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return -1.f;
+    DBuf a;
+    a.alloc(4096);
+    if (variant == 2)
+        hipFuncSetAttribute((const void*)chain_empty_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    BigArgs ba;
+    memset(&ba, 0, sizeof(ba));
+    auto chain = [&]() {
+        for (int k = 0; k < n_kernels; k++) {
+            if (variant == 1) hipLaunchKernelGGL(chain_fat_vgpr_kernel, dim3(blocks), dim3(threads), 0, s, (float*)a.p);
+            else if (variant == 2) hipLaunchKernelGGL(chain_empty_kernel, dim3(blocks), dim3(threads), 80 * 1024, s, (float*)a.p);
+            else if (variant == 3) hipLaunchKernelGGL(chain_bigargs_kernel, dim3(blocks), dim3(threads), 0, s, ba);
+            else hipLaunchKernelGGL(chain_empty_kernel, dim3(blocks), dim3(threads), 0, s, (float*)a.p);
+        }
+    };
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    chain();
+    hipStreamSynchronize(s);
+    hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
+    chain();
+    if (hipStreamEndCapture(s, &g) != hipSuccess) return -1.f;
+    if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) return -1.f;
+    hipGraphLaunch(ge, s);
+    hipStreamSynchronize(s);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventRecord(e0, s);
+    for (int it = 0; it < iters; it++) hipGraphLaunch(ge, s);
+    hipEventRecord(e1, s);
+    hipStreamSynchronize(s);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipGraphExecDestroy(ge);
+    hipGraphDestroy(g);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipStreamDestroy(s);
+    return ms * 1000.f / ((float)iters * n_kernels);
+}
