@@ -38,6 +38,7 @@ struct ConvArgs {
     int n_tiles = 0, tiles_l = 0, tiles_m = 0;  // set by the launcher
 };
 
+static int g_voc_split = 0;    // 0 (default): exact-fp32 MFMA everywhere; 1: split-precision fp16 MFMA path where Cin % 16 == 0
 static int g_voc_max_wgs = 0;  // 0 = one workgroup per tile; >0 caps the grid (persistent tile loop)
 constexpr int VKC = 8;     // input channels per LDS stage
 constexpr int VTN = 128;   // output columns per workgroup (4 waves x 32)
@@ -184,6 +185,171 @@ static int launch_conv(hipStream_t s, const ConvArgs& a, int B) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Split-precision path: fp32-equivalent products on the fp16 MFMA (16x the rate of the exact-fp32 MFMA).
+// Every operand v is carried as two fp16 terms: hi = fp16(v), lo = fp16((v - hi) * 2048) (22 mantissa bits
+// together; the scale keeps lo out of the subnormals).  a*b ~= hi_a*hi_b + (hi_a*lo_b + lo_a*hi_b)/2048,
+// three v_mfma_f32_32x32x16_f16 with f32 accumulation (products of fp16 values are exact in f32); the
+// dropped lo*lo term is 2^-22 relative.  Weights are split once at load, activations while they are staged
+// into LDS (after Snake, which stays in f32).  K dimension of the MFMA = input channels (16 per instruction);
+// a tap is a shifted row window of the channel-minor input image, so LDS rows are [column][ci].
+// ---------------------------------------------------------------------------
+typedef _Float16 hv8 __attribute__((ext_vector_type(8)));
+typedef _Float16 hv4 __attribute__((ext_vector_type(4)));
+
+struct SplitArgs {
+    const float* x = nullptr;            // [B][Cin][Lin] f32
+    float* y = nullptr;
+    const _Float16* w_hi = nullptr;      // [Cin/16][K][Mp][16]  (Mp = rows padded to 128)
+    const _Float16* w_lo = nullptr;
+    const float* bias = nullptr;
+    const float* alpha = nullptr;
+    const float* inv_beta = nullptr;
+    const float* res = nullptr;
+    int Cin = 0, M = 0, Mp = 0, dil = 1, Lin = 0, stride = 1, Cout = 0, clamp = 0;
+    int n_tiles = 0, tiles_l = 0, tiles_m = 0;
+};
+
+constexpr int STM = 128, STN = 128, SKC = 16;  // workgroup tile and input channels per stage
+
+template <int KT>
+__global__ void __launch_bounds__(256) conv_split_kernel(SplitArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1;                 // 2x2 waves, 64 rows x 64 columns each
+    const int halo = (KT - 1) * a.dil;
+    const int XW = STN + halo;
+    extern __shared__ __attribute__((aligned(16))) char slds[];
+    _Float16* Wh = (_Float16*)slds;                    // [KT][STM][16]
+    _Float16* Wl = Wh + KT * STM * SKC;
+    _Float16* Xh = Wl + KT * STM * SKC;                // [XW][16]
+    _Float16* Xl = Xh + (size_t)XW * SKC;
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int lx = tile % a.tiles_l, my = (tile / a.tiles_l) % a.tiles_m, b = tile / (a.tiles_l * a.tiles_m);
+        const int l0 = lx * STN, m0 = my * STM;
+        const float* xb = a.x + (size_t)b * a.Cin * a.Lin;
+        f16v acc[2][2], accx[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    acc[i][j][r] = 0.f;
+                    accx[i][j][r] = 0.f;
+                }
+        for (int ci0 = 0; ci0 < a.Cin; ci0 += SKC) {
+            __syncthreads();
+            // weights: the stage's [k][128 rows][16 ci] blocks are contiguous 4 KiB runs in the packed arrays
+            for (int idx = tid; idx < KT * STM * 2; idx += 256) {      // 16-byte pieces
+                const int piece = idx & 1, mm = (idx >> 1) % STM, k = (idx >> 1) / STM;
+                const size_t g = ((((size_t)(ci0 >> 4) * KT + k) * a.Mp) + m0 + mm) * SKC + piece * 8;
+                *(hv8*)(Wh + (k * STM + mm) * SKC + piece * 8) = *(const hv8*)(a.w_hi + g);
+                *(hv8*)(Wl + (k * STM + mm) * SKC + piece * 8) = *(const hv8*)(a.w_lo + g);
+            }
+            // input: 4 channels x 1 column per item; Snake in f32, then the hi/lo split
+            for (int idx = tid; idx < 4 * XW; idx += 256) {
+                const int qd = idx / XW, col = idx - qd * XW;
+                const int l = l0 - halo + col;
+                hv4 vh, vl;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int ci = ci0 + qd * 4 + j;
+                    float v = 0.f;
+                    if (l >= 0 && l < a.Lin) {
+                        v = xb[(size_t)ci * a.Lin + l];
+                        if (a.alpha) {
+                            const float sn = __sinf(a.alpha[ci] * v);
+                            v = v + a.inv_beta[ci] * (sn * sn);
+                        }
+                    }
+                    const _Float16 hi = (_Float16)v;
+                    vh[j] = hi;
+                    vl[j] = (_Float16)((v - (float)hi) * 2048.0f);
+                }
+                *(hv4*)(Xh + (size_t)col * SKC + qd * 4) = vh;
+                *(hv4*)(Xl + (size_t)col * SKC + qd * 4) = vl;
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int k = 0; k < KT; k++) {
+                const int off = halo - (KT - 1 - k) * a.dil;
+                hv8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const int row = wr * 64 + i * 32 + (lane & 31);
+                    ah[i] = *(const hv8*)(Wh + (k * STM + row) * SKC + (lane >> 5) * 8);
+                    al[i] = *(const hv8*)(Wl + (k * STM + row) * SKC + (lane >> 5) * 8);
+                    const int col = wc * 64 + i * 32 + (lane & 31) + off;
+                    bh[i] = *(const hv8*)(Xh + (size_t)col * SKC + (lane >> 5) * 8);
+                    bl[i] = *(const hv8*)(Xl + (size_t)col * SKC + (lane >> 5) * 8);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+                    }
+            }
+        }
+        const int Lout = a.Lin * a.stride;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int l = l0 + wc * 64 + j * 32 + (lane & 31);
+                if (l < a.Lin) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        if (m < a.M) {
+                            const int co = a.stride == 1 ? m : m / a.stride;
+                            const int p = a.stride == 1 ? 0 : m % a.stride;
+                            const size_t idx = ((size_t)b * a.Cout + co) * Lout + (size_t)l * a.stride + p;
+                            float v = acc[i][j][r] + accx[i][j][r] * (1.0f / 2048.0f);
+                            if (a.bias) v += a.bias[co];
+                            if (a.res) v += a.res[idx];
+                            if (a.clamp) v = fminf(fmaxf(v, -1.f), 1.f);
+                            a.y[idx] = v;
+                        }
+                    }
+                }
+            }
+    }
+}
+
+template <int KT>
+static int launch_conv_split_t(hipStream_t s, const SplitArgs& a, int B) {
+    if (a.dil > 9) return -1;
+    const int halo = (KT - 1) * a.dil;
+    const size_t lds = ((size_t)2 * KT * STM * SKC + (size_t)2 * (STN + halo) * SKC) * sizeof(_Float16);
+    static bool set_ = false;
+    if (!set_ && lds > 48 * 1024) {
+        Q3_HIP(hipFuncSetAttribute((const void*)conv_split_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), -1);
+        set_ = true;
+    }
+    SplitArgs c = a;
+    c.tiles_l = (a.Lin + STN - 1) / STN;
+    c.tiles_m = (a.M + STM - 1) / STM;
+    c.n_tiles = c.tiles_l * c.tiles_m * B;
+    int grid = c.n_tiles;
+    if (g_voc_max_wgs > 0 && grid > g_voc_max_wgs) grid = g_voc_max_wgs;
+    hipLaunchKernelGGL((conv_split_kernel<KT>), dim3(grid), dim3(256), lds, s, c);
+    Q3_HIP(hipGetLastError(), -1);
+    return 0;
+}
+
+static int launch_conv_split(hipStream_t s, const SplitArgs& a, int K, int B) {
+    switch (K) {
+        case 1: return launch_conv_split_t<1>(s, a, B);
+        case 2: return launch_conv_split_t<2>(s, a, B);
+        case 3: return launch_conv_split_t<3>(s, a, B);
+        case 7: return launch_conv_split_t<7>(s, a, B);
+        default: return -1;
+    }
+}
+
 // Split residual VQ de-quantisation: codes i64 [B][T][NQ] -> y [B][OUT][T].
 // Quantiser 0 (semantic) and 1..NQ-1 (acoustic) each sum their codebook rows ([NQ][CB][DIM]) and go
 // through their own DIM->OUT projection (1x1 conv without bias); the two results add.
@@ -216,6 +382,8 @@ __global__ void __launch_bounds__(256) rvq_kernel(const int64_t* __restrict__ co
 struct VocOp {
     int op = 0, cin = 0, cout = 0, k = 0, p0 = 0, flags = 0, nq = 0, cb = 0;
     float *w = nullptr, *bias = nullptr, *alpha = nullptr, *inv_beta = nullptr;  // device
+    _Float16 *w_hi = nullptr, *w_lo = nullptr;  // split-precision weights (null: exact path only)
+    int Mp128 = 0;
     float *p_sem = nullptr, *p_ac = nullptr;
 };
 
@@ -294,6 +462,7 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
         Q3_LOG("%s holds no vocoder program (tensor voc.program int32 [n][8])", weights);
         return nullptr;
     }
+    if (const char* sp = getenv("Q3_VOC_SPLIT")) g_voc_split = atoi(sp) ? 1 : 0;
     Voc* v = new Voc();
     v->chunk = chunk_tokens > 0 ? chunk_tokens : 64;
     v->max_batch = max_batch > 0 ? max_batch : 1;
@@ -401,6 +570,34 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
                                 wk[((size_t)(J - 1 - j) * op.cout * s + (size_t)co * s + ph) * op.cin + ci] =
                                     src[((size_t)ci * op.cout + co) * op.k + ph + j * s];
             }
+            if (op.cin % 16 == 0) {   // split-precision copy: [cin/16][tap][Mp128][16] hi / lo fp16
+                const int KTAPS = op.op == VOP_CONV ? op.k : op.k / op.p0;
+                const int Mrows = op.op == VOP_CONV ? op.cout : op.cout * op.p0;
+                const int Mp = (Mrows + 127) / 128 * 128;
+                std::vector<uint16_t> hi((size_t)(op.cin / 16) * KTAPS * Mp * 16, 0), lo(hi.size(), 0);
+                for (int k = 0; k < KTAPS; k++)
+                    for (int m = 0; m < Mrows; m++)
+                        for (int ci = 0; ci < op.cin; ci++) {
+                            const float wv = wk[((size_t)k * Mrows + m) * op.cin + ci];
+                            const uint16_t h = f2h_sat(wv);
+                            const size_t d = ((((size_t)(ci >> 4) * KTAPS + k) * Mp) + m) * 16 + (ci & 15);
+                            hi[d] = h;
+                            lo[d] = f2h_sat((wv - h2f(h)) * 2048.0f);
+                        }
+                void *dh = nullptr, *dl = nullptr;
+                if (hipMalloc(&dh, hi.size() * 2) != hipSuccess || hipMalloc(&dl, lo.size() * 2) != hipSuccess) {
+                    ok = false;
+                    break;
+                }
+                v->allocs.push_back(dh);
+                v->allocs.push_back(dl);
+                ok = hipMemcpy(dh, hi.data(), hi.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
+                     hipMemcpy(dl, lo.data(), lo.size() * 2, hipMemcpyHostToDevice) == hipSuccess;
+                op.w_hi = (_Float16*)dh;
+                op.w_lo = (_Float16*)dl;
+                op.Mp128 = Mp;
+                if (!ok) break;
+            }
             {   // [tap][row][cin] -> stage-major [cin/8][tap][cin%8][Mp]
                 const int KTAPS = op.op == VOP_CONV ? op.k : op.k / op.p0;
                 const int Mrows = op.op == VOP_CONV ? op.cout : op.cout * op.p0;
@@ -467,6 +664,11 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
 }
 
 // Cap the number of workgroups every vocoder launch may occupy (0 = no cap).  Process-wide.
+int voc_set_exact_fp32(int on) {
+    g_voc_split = on ? 0 : 1;
+    return 0;
+}
+
 int voc_set_max_workgroups(int n) {
     g_voc_max_wgs = n < 0 ? 0 : n;
     return 0;
@@ -524,7 +726,28 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
                 res = v->buf[2];
             }
             if (op.flags & VF_RES_ADD) a.res = res;
-            if (launch_conv(v->s, a, B)) return -1;
+            if (g_voc_split && op.w_hi) {
+                SplitArgs sa;
+                sa.x = a.x;
+                sa.y = a.y;
+                sa.w_hi = op.w_hi;
+                sa.w_lo = op.w_lo;
+                sa.bias = a.bias;
+                sa.alpha = a.alpha;
+                sa.inv_beta = a.inv_beta;
+                sa.res = a.res;
+                sa.Cin = a.Cin;
+                sa.M = a.M;
+                sa.Mp = op.Mp128;
+                sa.dil = a.dil;
+                sa.Lin = a.Lin;
+                sa.stride = a.stride;
+                sa.Cout = a.Cout;
+                sa.clamp = a.clamp;
+                if (launch_conv_split(v->s, sa, a.K, B)) return -1;
+            } else if (launch_conv(v->s, a, B)) {
+                return -1;
+            }
             C = op.cout;
             if (op.op == VOP_CONVT) L *= op.p0;
         }
