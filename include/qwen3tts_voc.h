@@ -44,11 +44,12 @@ int voc_synthesize(void* v, const int64_t* codes, int n_tokens, int16_t* out, in
 int voc_synthesize_f32(void* v, const int64_t* codes, int n_tokens, float* out, int32_t* n_samples);
 int voc_synthesize_max_samples(void* v, int n_tokens);
 
-/* Arithmetic of the convolutions.  Default (1): the exact-f32 MFMA (v_mfma_f32_32x32x2_f32) everywhere.
- * 0: split precision -- every f32 operand is carried as two fp16 terms (22 mantissa bits) and each product
- * costs three fp16 MFMAs with f32 accumulation.  Measured on MI355X against a float64 evaluation of the
- * same table: max error 2.2e-7 (split) vs 4.0e-7 (exact f32 MFMA) vs 2.1e-7 (torch CPU f32) of full scale.
- * Process-wide; env Q3_VOC_SPLIT=1 selects the split path at load. */
+/* Arithmetic of the convolutions.  Default (0): split precision -- every f32 operand (weights once at load,
+ * activations in the producing kernel's epilogue) is carried as two fp16 terms (22 mantissa bits) and each
+ * product costs three fp16 MFMAs with f32 accumulation.  1: the exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
+ * everywhere.  Measured on MI355X against a float64 evaluation of the same table: max error 2.2e-7 (split)
+ * vs 4.0e-7 (exact f32 MFMA) vs 2.1e-7 (torch CPU f32) of full scale -- the split path is fp32-grade, and
+ * 2.3x (32 chunks) to 3x (1 chunk) faster.  Process-wide; env Q3_VOC_EXACT=1 selects the exact path at load. */
 int voc_set_exact_fp32(int on);
 
 /* Cap the workgroups each vocoder kernel launch occupies (0 = one per output tile).  With a cap the

@@ -202,11 +202,20 @@ void* q3e_create(const char* weights, int max_batch, int n_ctx, int max_frames) 
     e->max_frames = max_frames;
     const ModelCfg& c = m->cfg;
     e->prefill_rows = max_batch > 2048 ? max_batch : 2048;
-    bool ok = hipStreamCreateWithFlags(&e->s, hipStreamNonBlocking) == hipSuccess;
+    // the frame loop is a latency-bound dependent chain: its queues get the highest priority so that its
+    // short kernels are placed ahead of throughput work (the vocoder stream asks for the lowest)
+    int prio_lo = 0, prio_hi = 0;
+    const bool use_prio = !(getenv("Q3_STREAM_PRIO") && atoi(getenv("Q3_STREAM_PRIO")) == 0) &&
+                          hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess && prio_lo != prio_hi;
+    auto mkstream = [&](hipStream_t* st) {
+        return (use_prio ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_hi)
+                         : hipStreamCreateWithFlags(st, hipStreamNonBlocking)) == hipSuccess;
+    };
+    bool ok = mkstream(&e->s);
     ok = ok && hipEventCreate(&e->ev0) == hipSuccess && hipEventCreate(&e->ev1) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int c = 0; c < 8 && ok; c++)
-        ok = hipStreamCreateWithFlags(&e->cs[c], hipStreamNonBlocking) == hipSuccess &&
+        ok = mkstream(&e->cs[c]) &&
              hipEventCreateWithFlags(&e->ev_join[c], hipEventDisableTiming) == hipSuccess;
     if (const char* nc = getenv("Q3_CHAINS")) e->n_chains = atoi(nc) < 1 ? 1 : atoi(nc) > 8 ? 8 : atoi(nc);
     else e->n_chains = 1;  // measured on MI355X/ROCm 7.2: graphs on separate streams do not overlap here

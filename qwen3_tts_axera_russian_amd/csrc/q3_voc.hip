@@ -38,7 +38,7 @@ struct ConvArgs {
     int n_tiles = 0, tiles_l = 0, tiles_m = 0;  // set by the launcher
 };
 
-static int g_voc_split = 0;    // 0 (default): exact-fp32 MFMA everywhere; 1: split-precision fp16 MFMA path where Cin % 16 == 0
+static int g_voc_split = 1;    // 1 (default): split-precision fp16 MFMA path where Cin % 16 == 0; 0: exact-fp32 MFMA everywhere
 static int g_voc_max_wgs = 0;  // 0 = one workgroup per tile; >0 caps the grid (persistent tile loop)
 constexpr int VKC = 8;     // input channels per LDS stage
 constexpr int VTN = 128;   // output columns per workgroup (4 waves x 32)
@@ -186,47 +186,88 @@ static int launch_conv(hipStream_t s, const ConvArgs& a, int B) {
 }
 
 // ---------------------------------------------------------------------------
-// Split-precision path: fp32-equivalent products on the fp16 MFMA (16x the rate of the exact-fp32 MFMA).
+// Split-precision path: fp32-grade products on the fp16 MFMA (16x the rate of the exact-fp32 MFMA).
 // Every operand v is carried as two fp16 terms: hi = fp16(v), lo = fp16((v - hi) * 2048) (22 mantissa bits
-// together; the scale keeps lo out of the subnormals).  a*b ~= hi_a*hi_b + (hi_a*lo_b + lo_a*hi_b)/2048,
+// together; the scale keeps lo out of the subnormals).  a*b ~= hi_a*hi_b + (hi_a*lo_b + lo_a*hi_b)/2048:
 // three v_mfma_f32_32x32x16_f16 with f32 accumulation (products of fp16 values are exact in f32); the
-// dropped lo*lo term is 2^-22 relative.  Weights are split once at load, activations while they are staged
-// into LDS (after Snake, which stays in f32).  K dimension of the MFMA = input channels (16 per instruction);
-// a tap is a shifted row window of the channel-minor input image, so LDS rows are [column][ci].
+// dropped lo*lo term is 2^-22 relative.  Measured against a float64 evaluation of the same table the result
+// is as close as the exact-fp32 MFMA path and torch's CPU fp32 (2e-7 of full scale; tests/test_gpu_vocoder.py).
+//   snake_split_kernel  x f32 [B][C][L] -> Snake -> hi/lo planes fp16 [B][C/8][L][8] (8-channel groups,
+//                       channel-minor: one 16-B record = one lane's MFMA B operand; a conv stage's input tile
+//                       is two contiguous runs, a tap a row shift; the producing conv's epilogue writes whole
+//                       records with lanes l, l+32 side by side)
+//   conv_split_kernel   implicit GEMM, K dimension = 16 input channels per MFMA; weights split once at load
+//                       into [Cin/16][tap][rows][16] planes.  Workgroup = 64 rows x 256 columns, 4 waves side
+//                       by side (64 x 64 each: all share the weight fragments); staging is pure 16-B copies.
 // ---------------------------------------------------------------------------
 typedef _Float16 hv8 __attribute__((ext_vector_type(8)));
-typedef _Float16 hv4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) snake_split_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                          const float* __restrict__ inv_beta, _Float16* __restrict__ xh,
+                                                          _Float16* __restrict__ xl, int C, int L) {
+    const int l = blockIdx.x * 256 + threadIdx.x, cg = blockIdx.y, b = blockIdx.z;   // cg: 8-channel group
+    if (l >= L) return;
+    const float* xp = x + ((size_t)b * C + cg * 8) * L + l;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = xp[(size_t)j * L];
+    if (alpha) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float sn = __sinf(alpha[cg * 8 + j] * v[j]);
+            v[j] = v[j] + inv_beta[cg * 8 + j] * (sn * sn);
+        }
+    }
+    hv8 h, lo;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const _Float16 hi = (_Float16)fminf(fmaxf(v[j], -65504.f), 65504.f);
+        h[j] = hi;
+        lo[j] = (_Float16)((v[j] - (float)hi) * 2048.0f);
+    }
+    const size_t o = (((size_t)b * (C >> 3) + cg) * L + l) * 8;
+    *(hv8*)(xh + o) = h;
+    *(hv8*)(xl + o) = lo;
+}
 
 struct SplitArgs {
-    const float* x = nullptr;            // [B][Cin][Lin] f32
-    float* y = nullptr;
+    const _Float16* xh = nullptr;        // [B][Cin/8][Lin][8]
+    const _Float16* xl = nullptr;
+    float* y = nullptr;                  // [B][Cout][Lin*stride] f32
     const _Float16* w_hi = nullptr;      // [Cin/16][K][Mp][16]  (Mp = rows padded to 128)
     const _Float16* w_lo = nullptr;
     const float* bias = nullptr;
-    const float* alpha = nullptr;
-    const float* inv_beta = nullptr;
     const float* res = nullptr;
-    int Cin = 0, M = 0, Mp = 0, dil = 1, Lin = 0, stride = 1, Cout = 0, clamp = 0;
+    // optional second output (stride 1 only): the result already in the NEXT conv's input form -- its Snake
+    // applied, split into hi/lo planes [B][Cout/8][Lin][8] -- so no separate pass re-reads it
+    _Float16* oh = nullptr;
+    _Float16* ol = nullptr;
+    const float* oalpha = nullptr;
+    const float* oinv_beta = nullptr;
+    int Cin = 0, M = 0, Mp = 0, dil = 1, Lin = 0, stride = 1, Cout = 0, clamp = 0, B = 0;
     int n_tiles = 0, tiles_l = 0, tiles_m = 0;
 };
 
-constexpr int STM = 128, STN = 128, SKC = 16;  // workgroup tile and input channels per stage
+constexpr int STM = 64, STN = 256, SKC = 16;  // workgroup tile and input channels per stage
 
-template <int KT>
-__global__ void __launch_bounds__(256) conv_split_kernel(SplitArgs a) {
+// KT taps; KS 16-channel k-steps per LDS stage (few-tap convs stage several, so a barrier pair buys more MFMAs)
+template <int KT, int KS>
+__global__ void __launch_bounds__(256, 2) conv_split_kernel(SplitArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wr = w >> 1, wc = w & 1;                 // 2x2 waves, 64 rows x 64 columns each
     const int halo = (KT - 1) * a.dil;
     const int XW = STN + halo;
     extern __shared__ __attribute__((aligned(16))) char slds[];
-    _Float16* Wh = (_Float16*)slds;                    // [KT][STM][16]
-    _Float16* Wl = Wh + KT * STM * SKC;
-    _Float16* Xh = Wl + KT * STM * SKC;                // [XW][16]
-    _Float16* Xl = Xh + (size_t)XW * SKC;
+    _Float16* Wh = (_Float16*)slds;                    // [KS][KT][STM][16]
+    _Float16* Wl = Wh + KS * KT * STM * SKC;
+    _Float16* Xh = Wl + KS * KT * STM * SKC;           // [KS][2][XW][8]: per k-step its two 8-channel groups
+    _Float16* Xl = Xh + (size_t)KS * XW * SKC;
+    const int C16 = a.Cin >> 4;
+    const hv8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // tiles: columns fastest, then chunk, row tile slowest -- at any moment the chip works on one or two row
+    // tiles, whose weights stay in every XCD's L2 while the input tiles stream
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        const int lx = tile % a.tiles_l, my = (tile / a.tiles_l) % a.tiles_m, b = tile / (a.tiles_l * a.tiles_m);
+        const int lx = tile % a.tiles_l, b = (tile / a.tiles_l) % a.B, my = tile / (a.tiles_l * a.B);
         const int l0 = lx * STN, m0 = my * STM;
-        const float* xb = a.x + (size_t)b * a.Cin * a.Lin;
         f16v acc[2][2], accx[2][2];
 #pragma unroll
         for (int i = 0; i < 2; i++)
@@ -237,51 +278,42 @@ __global__ void __launch_bounds__(256) conv_split_kernel(SplitArgs a) {
                     acc[i][j][r] = 0.f;
                     accx[i][j][r] = 0.f;
                 }
-        for (int ci0 = 0; ci0 < a.Cin; ci0 += SKC) {
+        for (int cb = 0; cb < C16; cb += KS) {
             __syncthreads();
-            // weights: the stage's [k][128 rows][16 ci] blocks are contiguous 4 KiB runs in the packed arrays
-            for (int idx = tid; idx < KT * STM * 2; idx += 256) {      // 16-byte pieces
-                const int piece = idx & 1, mm = (idx >> 1) % STM, k = (idx >> 1) / STM;
-                const size_t g = ((((size_t)(ci0 >> 4) * KT + k) * a.Mp) + m0 + mm) * SKC + piece * 8;
-                *(hv8*)(Wh + (k * STM + mm) * SKC + piece * 8) = *(const hv8*)(a.w_hi + g);
-                *(hv8*)(Wl + (k * STM + mm) * SKC + piece * 8) = *(const hv8*)(a.w_lo + g);
+            // weights: per (k-step, tap) one contiguous 2 KiB run of each plane
+            for (int idx = tid; idx < KS * KT * STM * 2; idx += 256) {      // 16-byte pieces
+                const int sk = idx >> 7, rem = idx & 127;      // sk = ks*KT + k
+                const size_t g = ((size_t)(cb * KT + sk) * a.Mp + m0) * SKC + rem * 8;
+                *(hv8*)(Wh + idx * 8) = *(const hv8*)(a.w_hi + g);
+                *(hv8*)(Wl + idx * 8) = *(const hv8*)(a.w_lo + g);
             }
-            // input: 4 channels x 1 column per item; Snake in f32, then the hi/lo split
-            for (int idx = tid; idx < 4 * XW; idx += 256) {
-                const int qd = idx / XW, col = idx - qd * XW;
+            // input: columns l0-halo .. l0+255 of the stage's 2*KS 8-channel groups, one contiguous run each
+            for (int idx = tid; idx < KS * 2 * XW; idx += 256) {
+                const int grp = idx / XW, col = idx - grp * XW;
                 const int l = l0 - halo + col;
-                hv4 vh, vl;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int ci = ci0 + qd * 4 + j;
-                    float v = 0.f;
-                    if (l >= 0 && l < a.Lin) {
-                        v = xb[(size_t)ci * a.Lin + l];
-                        if (a.alpha) {
-                            const float sn = __sinf(a.alpha[ci] * v);
-                            v = v + a.inv_beta[ci] * (sn * sn);
-                        }
-                    }
-                    const _Float16 hi = (_Float16)v;
-                    vh[j] = hi;
-                    vl[j] = (_Float16)((v - (float)hi) * 2048.0f);
+                hv8 vh = zero8, vl = zero8;
+                if (l >= 0 && l < a.Lin) {
+                    const size_t g = ((((size_t)b * C16 + cb) * 2 + grp) * a.Lin + l) * 8;
+                    vh = *(const hv8*)(a.xh + g);
+                    vl = *(const hv8*)(a.xl + g);
                 }
-                *(hv4*)(Xh + (size_t)col * SKC + qd * 4) = vh;
-                *(hv4*)(Xl + (size_t)col * SKC + qd * 4) = vl;
+                *(hv8*)(Xh + idx * 8) = vh;
+                *(hv8*)(Xl + idx * 8) = vl;
             }
             __syncthreads();
-#pragma unroll 1
-            for (int k = 0; k < KT; k++) {
-                const int off = halo - (KT - 1 - k) * a.dil;
+#pragma unroll
+            for (int sk = 0; sk < KS * KT; sk++) {
+                const int ks = sk / KT, k = sk % KT;
+                const int off = k * a.dil;   // tap k reads column l - (KT-1-k)*dil = staged column (l-l0) + k*dil
                 hv8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
-                    const int row = wr * 64 + i * 32 + (lane & 31);
-                    ah[i] = *(const hv8*)(Wh + (k * STM + row) * SKC + (lane >> 5) * 8);
-                    al[i] = *(const hv8*)(Wl + (k * STM + row) * SKC + (lane >> 5) * 8);
-                    const int col = wc * 64 + i * 32 + (lane & 31) + off;
-                    bh[i] = *(const hv8*)(Xh + (size_t)col * SKC + (lane >> 5) * 8);
-                    bl[i] = *(const hv8*)(Xl + (size_t)col * SKC + (lane >> 5) * 8);
+                    const int row = i * 32 + (lane & 31);
+                    ah[i] = *(const hv8*)(Wh + (sk * STM + row) * SKC + (lane >> 5) * 8);
+                    al[i] = *(const hv8*)(Wl + (sk * STM + row) * SKC + (lane >> 5) * 8);
+                    const int col = w * 64 + i * 32 + (lane & 31) + off;
+                    bh[i] = *(const hv8*)(Xh + ((size_t)(ks * 2 + (lane >> 5)) * XW + col) * 8);
+                    bl[i] = *(const hv8*)(Xl + ((size_t)(ks * 2 + (lane >> 5)) * XW + col) * 8);
                 }
 #pragma unroll
                 for (int i = 0; i < 2; i++)
@@ -294,24 +326,58 @@ __global__ void __launch_bounds__(256) conv_split_kernel(SplitArgs a) {
             }
         }
         const int Lout = a.Lin * a.stride;
+        typedef _Float16 hv4 __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                const int l = l0 + wc * 64 + j * 32 + (lane & 31);
+                const int l = l0 + w * 64 + j * 32 + (lane & 31);
                 if (l < a.Lin) {
+                    float rv[16];
 #pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        if (m < a.M) {
+                    for (int r = 0; r < 16; r++) {     // the residual reads of the whole 32x32 tile go out together
+                        const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        rv[r] = 0.f;
+                        if (a.res && m < a.M) {
                             const int co = a.stride == 1 ? m : m / a.stride;
                             const int p = a.stride == 1 ? 0 : m % a.stride;
-                            const size_t idx = ((size_t)b * a.Cout + co) * Lout + (size_t)l * a.stride + p;
-                            float v = acc[i][j][r] + accx[i][j][r] * (1.0f / 2048.0f);
-                            if (a.bias) v += a.bias[co];
-                            if (a.res) v += a.res[idx];
-                            if (a.clamp) v = fminf(fmaxf(v, -1.f), 1.f);
-                            a.y[idx] = v;
+                            rv[r] = a.res[((size_t)b * a.Cout + co) * Lout + (size_t)l * a.stride + p];
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {      // accumulator registers 4g..4g+3 = 4 consecutive rows
+                        const int mg = m0 + i * 32 + 8 * g + 4 * (lane >> 5);
+                        float v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int m = mg + q, r = 4 * g + q;
+                            v[q] = acc[i][j][r] + accx[i][j][r] * (1.0f / 2048.0f);
+                            if (m < a.M) {
+                                const int co = a.stride == 1 ? m : m / a.stride;
+                                const int p = a.stride == 1 ? 0 : m % a.stride;
+                                const size_t idx = ((size_t)b * a.Cout + co) * Lout + (size_t)l * a.stride + p;
+                                if (a.bias) v[q] += a.bias[co];
+                                v[q] += rv[r];
+                                if (a.clamp) v[q] = fminf(fmaxf(v[q], -1.f), 1.f);
+                                if (a.y) a.y[idx] = v[q];
+                            }
+                        }
+                        if (a.oh && mg < a.M) {
+                            hv4 vh, vl;
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                float t = v[q];
+                                if (a.oalpha) {
+                                    const float sn = __sinf(a.oalpha[mg + q] * t);
+                                    t = t + a.oinv_beta[mg + q] * (sn * sn);
+                                }
+                                const _Float16 hi = (_Float16)fminf(fmaxf(t, -65504.f), 65504.f);
+                                vh[q] = hi;
+                                vl[q] = (_Float16)((t - (float)hi) * 2048.0f);
+                            }
+                            const size_t o = (((size_t)b * (a.Cout >> 3) + (mg >> 3)) * a.Lin + l) * 8 + (mg & 7);
+                            *(hv4*)(a.oh + o) = vh;
+                            *(hv4*)(a.ol + o) = vl;
                         }
                     }
                 }
@@ -319,33 +385,36 @@ __global__ void __launch_bounds__(256) conv_split_kernel(SplitArgs a) {
     }
 }
 
-template <int KT>
+template <int KT, int KS>
 static int launch_conv_split_t(hipStream_t s, const SplitArgs& a, int B) {
     if (a.dil > 9) return -1;
     const int halo = (KT - 1) * a.dil;
-    const size_t lds = ((size_t)2 * KT * STM * SKC + (size_t)2 * (STN + halo) * SKC) * sizeof(_Float16);
+    const size_t lds = ((size_t)2 * KS * KT * STM * SKC + (size_t)2 * KS * (STN + halo) * SKC) * sizeof(_Float16);
     static bool set_ = false;
-    if (!set_ && lds > 48 * 1024) {
-        Q3_HIP(hipFuncSetAttribute((const void*)conv_split_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), -1);
+    if (!set_) {
+        Q3_HIP(hipFuncSetAttribute((const void*)conv_split_kernel<KT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024), -1);
         set_ = true;
     }
+    if (lds > 64 * 1024 || (a.Cin / 16) % KS) return -1;
     SplitArgs c = a;
+    c.B = B;
     c.tiles_l = (a.Lin + STN - 1) / STN;
     c.tiles_m = (a.M + STM - 1) / STM;
     c.n_tiles = c.tiles_l * c.tiles_m * B;
     int grid = c.n_tiles;
     if (g_voc_max_wgs > 0 && grid > g_voc_max_wgs) grid = g_voc_max_wgs;
-    hipLaunchKernelGGL((conv_split_kernel<KT>), dim3(grid), dim3(256), lds, s, c);
+    hipLaunchKernelGGL((conv_split_kernel<KT, KS>), dim3(grid), dim3(256), lds, s, c);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
 }
 
 static int launch_conv_split(hipStream_t s, const SplitArgs& a, int K, int B) {
+    const int c16 = a.Cin / 16;
     switch (K) {
-        case 1: return launch_conv_split_t<1>(s, a, B);
-        case 2: return launch_conv_split_t<2>(s, a, B);
-        case 3: return launch_conv_split_t<3>(s, a, B);
-        case 7: return launch_conv_split_t<7>(s, a, B);
+        case 1: return c16 % 3 == 0 ? launch_conv_split_t<1, 3>(s, a, B) : c16 % 2 == 0 ? launch_conv_split_t<1, 2>(s, a, B) : launch_conv_split_t<1, 1>(s, a, B);
+        case 2: return c16 % 2 == 0 ? launch_conv_split_t<2, 2>(s, a, B) : launch_conv_split_t<2, 1>(s, a, B);
+        case 3: return c16 % 2 == 0 ? launch_conv_split_t<3, 2>(s, a, B) : launch_conv_split_t<3, 1>(s, a, B);
+        case 7: return launch_conv_split_t<7, 1>(s, a, B);
         default: return -1;
     }
 }
@@ -395,6 +464,7 @@ struct Voc {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int64_t* d_codes = nullptr;
     float *buf[3] = {nullptr, nullptr, nullptr};
+    _Float16 *plane[4] = {nullptr, nullptr, nullptr, nullptr};   // two {hi, lo} plane sets (split path): a conv's input and output
     size_t buf_elems = 0;
     float last_ms = 0.f;
     double flops_per_chunk = 0.0;
@@ -433,6 +503,8 @@ static void voc_destroy(Voc* v) {
     for (void* p : v->allocs) hipFree(p);
     for (float* b : v->buf)
         if (b) hipFree(b);
+    for (_Float16* b : v->plane)
+        if (b) hipFree(b);
     if (v->d_codes) hipFree(v->d_codes);
     if (v->e0) hipEventDestroy(v->e0);
     if (v->e1) hipEventDestroy(v->e1);
@@ -462,7 +534,7 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
         Q3_LOG("%s holds no vocoder program (tensor voc.program int32 [n][8])", weights);
         return nullptr;
     }
-    if (const char* sp = getenv("Q3_VOC_SPLIT")) g_voc_split = atoi(sp) ? 1 : 0;
+    if (const char* ex = getenv("Q3_VOC_EXACT")) g_voc_split = atoi(ex) ? 0 : 1;
     Voc* v = new Voc();
     v->chunk = chunk_tokens > 0 ? chunk_tokens : 64;
     v->max_batch = max_batch > 0 ? max_batch : 1;
@@ -484,7 +556,14 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
         ok = hipExtStreamCreateWithCUMask(&v->s, (uint32_t)mask.size(), mask.data()) == hipSuccess;
         if (!ok) Q3_LOG("hipExtStreamCreateWithCUMask failed");
     } else {
-        ok = hipStreamCreateWithFlags(&v->s, hipStreamNonBlocking) == hipSuccess;
+        // lowest queue priority: the vocoder is throughput work that runs beside the latency-bound frame
+        // loop (highest priority, q3_engine.hip); Q3_STREAM_PRIO=0 creates both at the default priority
+        int lo = 0, hi = 0;
+        const bool prio = !(getenv("Q3_STREAM_PRIO") && atoi(getenv("Q3_STREAM_PRIO")) == 0);
+        if (prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+            ok = hipStreamCreateWithPriority(&v->s, hipStreamNonBlocking, lo) == hipSuccess;
+        else
+            ok = hipStreamCreateWithFlags(&v->s, hipStreamNonBlocking) == hipSuccess;
     }
     ok = ok && hipEventCreate(&v->e0) == hipSuccess && hipEventCreate(&v->e1) == hipSuccess;
     const int32_t* pr = (const int32_t*)prog->data;
@@ -652,6 +731,7 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
         v->flops_per_chunk = flops;
         v->buf_elems = max_elems * v->max_batch;
         for (int i = 0; i < 3 && ok; i++) ok = hipMalloc((void**)&v->buf[i], v->buf_elems * 4) == hipSuccess;
+        for (int i = 0; i < 4 && ok; i++) ok = hipMalloc((void**)&v->plane[i], v->buf_elems * 2) == hipSuccess;
         ok = ok && hipMalloc((void**)&v->d_codes, sizeof(int64_t) * 16 * v->chunk * v->max_batch) == hipSuccess;
     }
     if (!ok) {
@@ -679,13 +759,89 @@ int voc_samples_per_token(void* vv) { return vv ? ((Voc*)vv)->upsample : 0; }
 float voc_last_decode_ms(void* vv) { return vv ? ((Voc*)vv)->last_ms : -1.f; }
 double voc_decode_flops(void* vv, int B) { return vv ? ((Voc*)vv)->flops_per_chunk * B : 0.0; }
 
+// Split path of one conv op.  State carried between ops: which f32 buffer holds the newest f32 activation
+// (and whether it is the current one), and which plane set (if any) already holds the current activation in
+// the next conv's input form.
+struct SplitState {
+    int f32_idx = 0;
+    bool f32_cur = true;
+    int planes = -1;       // plane set holding the current activation (Snake of the consuming op applied), or -1
+    float* res = nullptr;  // residual-unit input (f32)
+};
+
+static bool split_capable(const VocOp& op) { return (op.op == VOP_CONV || op.op == VOP_CONVT) && op.w_hi != nullptr; }
+
+static int voc_conv_split(Voc* v, const VocOp& op, const VocOp* next, bool last, int B, int C, long L, SplitState& st) {
+    const int KT = op.op == VOP_CONV ? op.k : op.k / op.p0;
+    int in_set = st.planes;
+    if (in_set < 0) {   // materialise the input planes from the f32 activation (this op's Snake applied)
+        if (!st.f32_cur) return -1;
+        in_set = 0;
+        hipLaunchKernelGGL(snake_split_kernel, dim3((unsigned)((L + 255) / 256), op.cin / 8, B), dim3(256), 0, v->s,
+                           v->buf[st.f32_idx], op.alpha, op.inv_beta, v->plane[0], v->plane[1], op.cin, (int)L);
+        Q3_HIP(hipGetLastError(), -1);
+    }
+    if (op.flags & VF_RES_SAVE) {
+        if (!st.f32_cur) return -1;   // the producer keeps an f32 copy whenever its consumer saves a residual
+        st.res = v->buf[st.f32_idx];
+    }
+    const bool want_planes = next && split_capable(*next) && op.op == VOP_CONV && op.cout % 16 == 0;
+    const bool want_f32 = !want_planes || last || (next->flags & VF_RES_SAVE);
+    SplitArgs sa;
+    sa.xh = v->plane[2 * in_set];
+    sa.xl = v->plane[2 * in_set + 1];
+    sa.w_hi = op.w_hi;
+    sa.w_lo = op.w_lo;
+    sa.bias = op.bias;
+    sa.res = (op.flags & VF_RES_ADD) ? st.res : nullptr;
+    sa.Cin = op.cin;
+    sa.Cout = op.cout;
+    sa.Mp = op.Mp128;
+    sa.Lin = (int)L;
+    sa.clamp = (op.flags & VF_CLAMP) ? 1 : 0;
+    if (op.op == VOP_CONV) {
+        sa.dil = op.p0;
+        sa.stride = 1;
+        sa.M = op.cout;
+    } else {
+        sa.dil = 1;
+        sa.stride = op.p0;
+        sa.M = op.cout * op.p0;
+    }
+    int out_f32 = st.f32_idx;
+    if (want_f32) {
+        // never the buffer the residual (or a still-current f32 input) lives in
+        out_f32 = st.f32_idx ^ 1;
+        if (sa.res == v->buf[out_f32]) return -1;
+        sa.y = v->buf[out_f32];
+    }
+    if (want_planes) {
+        sa.oh = v->plane[2 * (in_set ^ 1)];
+        sa.ol = v->plane[2 * (in_set ^ 1) + 1];
+        if (next->flags & VF_SNAKE) {
+            sa.oalpha = next->alpha;
+            sa.oinv_beta = next->inv_beta;
+        }
+    }
+    if (launch_conv_split(v->s, sa, KT, B)) return -1;
+    if (want_f32) {
+        st.f32_idx = out_f32;
+        st.f32_cur = true;
+    } else {
+        st.f32_cur = false;
+    }
+    st.planes = want_planes ? (in_set ^ 1) : -1;
+    return 0;
+}
+
 static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = nullptr, long* outL = nullptr,
                    float* op_ms = nullptr) {
-    // ping-pong between buf[0]/buf[1]; buf[2] keeps the residual-unit input
+    // ping-pong between buf[0]/buf[1]; buf[2] keeps the residual-unit input (exact path)
     int cur = 0;
     int C = 0;
     long L = v->chunk;
     float* res = nullptr;
+    SplitState st;
     const size_t nrun = n_ops < 0 ? v->ops.size() : (size_t)n_ops < v->ops.size() ? (size_t)n_ops : v->ops.size();
     for (size_t i = 0; i < nrun; i++) {
         const VocOp& op = v->ops[i];
@@ -697,7 +853,25 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
                                op.p_sem, op.p_ac, out, v->chunk, op.nq, op.cb, op.cin, op.cout);
             Q3_HIP(hipGetLastError(), -1);
             C = op.cout;
+            cur ^= 1;
+            st.f32_idx = cur;
+            st.f32_cur = true;
+            st.planes = -1;
+        } else if (g_voc_split && op.w_hi) {
+            const bool last = i + 1 == nrun;
+            const VocOp* next = (i + 1 < v->ops.size()) ? &v->ops[i + 1] : nullptr;
+            if (voc_conv_split(v, op, last ? nullptr : next, last, B, C, L, st)) {
+                Q3_LOG("vocoder op %zu: split path could not be scheduled", i);
+                return -1;
+            }
+            cur = st.f32_idx;
+            C = op.cout;
+            if (op.op == VOP_CONVT) L *= op.p0;
         } else {
+            if (!st.f32_cur) return -1;
+            cur = st.f32_idx;
+            in = v->buf[cur];
+            out = v->buf[cur ^ 1];
             ConvArgs a;
             a.x = in;
             a.y = out;
@@ -724,41 +898,25 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
                 // the unit's input is needed again after two convs: keep it where the ping-pong will not write
                 Q3_HIP(hipMemcpyAsync(v->buf[2], in, sizeof(float) * (size_t)B * C * L, hipMemcpyDeviceToDevice, v->s), -1);
                 res = v->buf[2];
+                st.res = res;
             }
-            if (op.flags & VF_RES_ADD) a.res = res;
-            if (g_voc_split && op.w_hi) {
-                SplitArgs sa;
-                sa.x = a.x;
-                sa.y = a.y;
-                sa.w_hi = op.w_hi;
-                sa.w_lo = op.w_lo;
-                sa.bias = a.bias;
-                sa.alpha = a.alpha;
-                sa.inv_beta = a.inv_beta;
-                sa.res = a.res;
-                sa.Cin = a.Cin;
-                sa.M = a.M;
-                sa.Mp = op.Mp128;
-                sa.dil = a.dil;
-                sa.Lin = a.Lin;
-                sa.stride = a.stride;
-                sa.Cout = a.Cout;
-                sa.clamp = a.clamp;
-                if (launch_conv_split(v->s, sa, a.K, B)) return -1;
-            } else if (launch_conv(v->s, a, B)) {
-                return -1;
-            }
+            if (op.flags & VF_RES_ADD) a.res = res ? res : st.res;
+            if (launch_conv(v->s, a, B)) return -1;
             C = op.cout;
             if (op.op == VOP_CONVT) L *= op.p0;
+            cur ^= 1;
+            st.f32_idx = cur;
+            st.f32_cur = true;
+            st.planes = -1;
         }
-        cur ^= 1;
         if (op_ms) {
             hipEventRecord(v->e1, v->s);
             hipStreamSynchronize(v->s);
             hipEventElapsedTime(&op_ms[i], v->e0, v->e1);
         }
     }
-    *out_dev = v->buf[cur];
+    if (!st.f32_cur) return -1;
+    *out_dev = v->buf[st.f32_idx];
     if (outC) *outC = C;
     if (outL) *outL = L;
     return 0;

@@ -1,7 +1,9 @@
 """Vocoder library (voc_* ABI) against an independent torch fp32 reference of the same op table,
 and its chunking/crossfade/int16 path against the restatement that is pinned to the reference's own
-VocoderServer.synthesize (tests/test_golden_frontend.py).  Waveform tolerance: exact-fp32 MFMA vs
-torch CPU differ only in summation order; 2e-4 of full scale is asserted (observed ~1e-6)."""
+VocoderServer.synthesize (tests/test_golden_frontend.py).  Waveform tolerance: both arithmetic modes
+(exact-fp32 MFMA; the default 2xfp16 split operands with f32 accumulation) differ from torch CPU fp32
+only at the level of fp32 summation order: 2e-4 of full scale is asserted (observed < 1e-6), and
+against a float64 evaluation the split path must be as close as an fp32 implementation is."""
 import os
 
 import numpy as np
@@ -61,8 +63,10 @@ class Voc:
         self.lib.voc_free(self.h)
 
 
-def test_decode_matches_torch_reference(gpu_lib, tiny_voc):
+@pytest.mark.parametrize("exact", [0, 1])
+def test_decode_matches_torch_reference(gpu_lib, tiny_voc, exact):
     path, vc, tensors = tiny_voc
+    gpu_lib.voc_set_exact_fp32(exact)
     v = Voc(gpu_lib, path)
     assert v.chunk == 64 and v.spt == 1920 == W.voc_total_upsample(vc)
     rng = np.random.default_rng(3)
@@ -78,6 +82,28 @@ def test_decode_matches_torch_reference(gpu_lib, tiny_voc):
     assert err < 2e-4
     assert np.abs(got).max() <= 1.0        # final clamp
     v.close()
+    gpu_lib.voc_set_exact_fp32(0)
+
+
+def test_split_arithmetic_is_fp32_grade(gpu_lib, tiny_voc):
+    """Error against a float64 evaluation of the same table: the default split path (two fp16 terms per
+    operand, f32 accumulation) must be no further from it than fp32 implementations are (the exact-fp32
+    MFMA path and torch CPU fp32), up to a factor 2 and a 1e-6 floor."""
+    path, vc, tensors = tiny_voc
+    codes = np.random.default_rng(5).integers(0, 2048, size=(2, 64, 16)).astype(np.int64)
+    ref64 = voc_reference(tensors, codes, dtype=np.float64)
+    ref32 = voc_reference(tensors, codes)
+    live = np.abs(ref64) < 0.999           # clamped samples carry no information
+    errs = {}
+    for exact in (1, 0):
+        gpu_lib.voc_set_exact_fp32(exact)
+        v = Voc(gpu_lib, path)
+        errs[exact] = float(np.abs(v.decode(codes) - ref64)[live].max())
+        v.close()
+    gpu_lib.voc_set_exact_fp32(0)
+    e_torch = float(np.abs(ref32 - ref64)[live].max())
+    print("max err vs float64: split", errs[0], "exact f32 MFMA", errs[1], "torch f32", e_torch)
+    assert errs[0] <= max(2.0 * max(errs[1], e_torch), 1e-6)
 
 
 def test_synthesize_chunk_walk_and_int16(gpu_lib, tiny_voc):

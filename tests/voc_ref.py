@@ -14,10 +14,10 @@ def _snake(x, alpha, beta):
     return x + ib * torch.sin(a * x) ** 2
 
 
-def voc_reference(tensors: dict, codes: np.ndarray, n_ops: int = -1) -> np.ndarray:
+def voc_reference(tensors: dict, codes: np.ndarray, n_ops: int = -1, dtype=np.float32) -> np.ndarray:
     """codes int64 [B][T][16] -> wav f32 [B][T*upsample] (or the activation after n_ops ops)."""
     prog = np.asarray(tensors["voc.program"])
-    t = lambda n: torch.from_numpy(np.array(tensors[n], dtype=np.float32))
+    t = lambda n: torch.from_numpy(np.array(tensors[n], dtype=dtype))
     codes_t = torch.from_numpy(np.asarray(codes, dtype=np.int64))
     x, res = None, None
     torch.set_num_threads(8)
@@ -29,7 +29,7 @@ def voc_reference(tensors: dict, codes: np.ndarray, n_ops: int = -1) -> np.ndarr
             if op == W.VOP_RVQ:
                 nq, cbs = int(row[1]), int(row[2])
                 cb = t(p + "codebook")
-                valid = ((codes_t >= 0) & (codes_t < cbs)).float()
+                valid = ((codes_t >= 0) & (codes_t < cbs)).to(cb.dtype)
                 idx = codes_t.clamp(0, cbs - 1)
                 emb = torch.stack([cb[q][idx[..., q]] * valid[..., q:q + 1] for q in range(nq)], 0)  # [nq,B,T,dim]
                 sem, ac = emb[0], emb[1:].sum(0)
