@@ -14,7 +14,10 @@
  * plus a line on stderr; no exceptions cross the boundary.
  *
  * `path` is this build's own packed fp16/fp32 weight file (Q3TTSW1 container,
- * see DESIGN.md), not a GGUF.  There is no CPU fallback: if no HIP device is
+ * see DESIGN.md), or -- parsed natively, no Python -- the safetensors file the
+ * reference's own converter writes before its GGUF step (re-keyed Qwen3 talker,
+ * scripts/extract_talker_as_qwen3.py:53-71), or the HF snapshot's
+ * model.safetensors / its directory; not a GGUF.  There is no CPU fallback: if no HIP device is
  * usable, wrapper_load_model returns NULL after printing the reason.
  */
 #ifndef QWEN3TTS_TALKER_H

@@ -17,7 +17,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib")
-SOURCES = ["q3_common.cpp", "q3_kernels.hip", "q3_model.hip", "q3_talker_api.hip", "q3_cp_api.hip",
+SOURCES = ["q3_common.cpp", "q3_formats.cpp", "q3_kernels.hip", "q3_model.hip", "q3_talker_api.hip", "q3_cp_api.hip",
            "q3_engine.hip", "q3_voc.hip", "q3_test_api.hip"]
 ARCH = os.environ.get("Q3_OFFLOAD_ARCH", "gfx950")
 # kernarg preload: the leading scalar kernel arguments arrive in SGPRs at wave launch (gfx940+)
@@ -52,7 +52,7 @@ def build(force: bool = False, verbose: bool = False, timeline: bool = False) ->
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     if force or not _newer(out, objs):
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs + ["-lz"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -103,6 +103,9 @@ bool Pack::open(const char* path) {
 }
 
 void Pack::close() {
+    for (auto& m : extra_maps) munmap(m.first, m.second);
+    extra_maps.clear();
+    owned.clear();
     if (map) munmap(map, map_size);
     map = nullptr;
     map_size = 0;

@@ -33,7 +33,7 @@ typedef _Float16 half_t;
 // ---------------------------------------------------------------------------
 // Q3TTSW1 container (written by weights.py)
 // ---------------------------------------------------------------------------
-enum DType : uint32_t { F32 = 0, F16 = 1, I32 = 2, I64 = 3 };
+enum DType : uint32_t { F32 = 0, F16 = 1, I32 = 2, I64 = 3, BF16 = 4 };   // BF16: safetensors only (q3_formats.cpp)
 
 struct PackTensor {
     std::string name;
@@ -56,6 +56,16 @@ struct Pack {
     int fd = -1;
 
     bool open(const char* path);
+    // the reference's deployed files instead of a container (q3_formats.cpp): .npy / .npz / .safetensors
+    // parsed natively, names mapped to the container's; `aux_dir` = the servers' --embeddings_dir
+    bool open_auto(const char* path, const char* aux_dir = nullptr);
+    bool add_npy(const char* path, const std::string& name);
+    bool add_npz(const char* path, std::string (*rename)(const std::string&));
+    bool add_safetensors(const char* path, std::string (*rename)(const std::string&));
+    bool add_npy_bytes(const uint8_t* p, size_t n, const std::string& name, const char* what);
+    const uint8_t* map_file(const char* path, size_t* size);
+    std::vector<std::pair<uint8_t*, size_t>> extra_maps;   // files mapped by the add_* readers
+    std::vector<std::vector<uint8_t>> owned;                // inflated / converted arrays
     void close();
     ~Pack() { close(); }
     const PackTensor* find(const std::string& n) const {
@@ -67,6 +77,16 @@ struct Pack {
         return it == meta.end() ? dflt : it->second;
     }
 };
+
+std::string map_cp_npz_key(const std::string& k);
+std::string map_safetensors_key(const std::string& k);
+
+inline float bf16_to_f32(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
 
 // host fp16 <-> fp32 (round to nearest even, saturating to +-65504)
 float h2f(uint16_t h);

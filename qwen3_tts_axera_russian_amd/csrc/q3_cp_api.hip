@@ -91,29 +91,16 @@ struct CpHandle {
     int step_next_pos = 0;
 };
 
-bool is_dir(const char* p) {
-    FILE* f = fopen(p, "rb");
-    if (!f) return false;
-    char b;
-    size_t n = fread(&b, 1, 1, f);
-    fclose(f);
-    return n == 0;  // fread on a directory fails
-}
-
 }  // namespace
 
 extern "C" {
 
 void* cp_load(const char* weights, const char* embeddings_dir, int max_batch) {
-    (void)embeddings_dir;
+    // `weights`: a Q3TTSW1 container, or the reference's --model_dir (code_predictor_weights.npz, parsed
+    // natively) with `embeddings_dir` = its --embeddings_dir (codec_embedding.npy): code_predictor_server.py:43-51
     if (!weights) return nullptr;
-    if (is_dir(weights)) {
-        Q3_LOG("cp_load: %s is a directory; convert the reference's npz/npy files with "
-               "`python -m qwen3_tts_axera_russian_amd.weights` first", weights);
-        return nullptr;
-    }
     if (max_batch <= 0) max_batch = 1;
-    Model* m = model_load(weights, false, true);
+    Model* m = model_load(weights, false, true, embeddings_dir);
     if (!m) return nullptr;
     CpHandle* h = new CpHandle();
     h->m = m;

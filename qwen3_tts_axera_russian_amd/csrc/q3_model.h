@@ -38,7 +38,8 @@ struct Model {
     size_t device_bytes = 0;
 };
 
-Model* model_load(const char* path, bool want_talker, bool want_cp);
+// `path`: a Q3TTSW1 container, or the reference's own files (Pack::open_auto); `aux_dir`: its --embeddings_dir
+Model* model_load(const char* path, bool want_talker, bool want_cp, const char* aux_dir = nullptr);
 void model_free(Model* m);
 
 struct KVCache {

@@ -35,7 +35,7 @@ struct Loader {
             return nullptr;
         }
         if (t->ndim != ndim || t->shape[0] != d0 || (ndim > 1 && t->shape[1] != d1) ||
-            (t->dtype != F32 && t->dtype != F16)) {
+            (t->dtype != F32 && t->dtype != F16 && t->dtype != BF16)) {
             Q3_LOG("tensor %s: unexpected shape/dtype", n.c_str());
             ok = false;
             return nullptr;
@@ -54,7 +54,10 @@ struct Loader {
         } else {
             std::vector<float> tmp(ne);
             const uint16_t* src = (const uint16_t*)t->data;
-            for (size_t i = 0; i < ne; i++) tmp[i] = h2f(src[i]);
+            if (t->dtype == BF16)
+                for (size_t i = 0; i < ne; i++) tmp[i] = bf16_to_f32(src[i]);
+            else
+                for (size_t i = 0; i < ne; i++) tmp[i] = h2f(src[i]);
             if (hipMemcpy(d, tmp.data(), ne * 4, hipMemcpyHostToDevice) != hipSuccess) ok = false;
         }
         return d;
@@ -78,6 +81,11 @@ struct Loader {
             host16.resize(ne);
             const float* f = (const float*)t->data;
             for (size_t i = 0; i < ne; i++) host16[i] = f2h_sat(f[i]);
+            src = host16.data();
+        } else if (t->dtype == BF16) {
+            host16.resize(ne);
+            const uint16_t* b = (const uint16_t*)t->data;
+            for (size_t i = 0; i < ne; i++) host16[i] = f2h_sat(bf16_to_f32(b[i]));
             src = host16.data();
         }
         if (hipMemcpy(stage, src, ne * 2, hipMemcpyHostToDevice) != hipSuccess) {
@@ -134,14 +142,14 @@ struct Loader {
 
 }  // namespace
 
-Model* model_load(const char* path, bool want_talker, bool want_cp) {
+Model* model_load(const char* path, bool want_talker, bool want_cp, const char* aux_dir) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         Q3_LOG("no HIP device available -- this library has no CPU path");
         return nullptr;
     }
     Pack p;
-    if (!p.open(path)) return nullptr;
+    if (!p.open_auto(path, aux_dir)) return nullptr;
     Model* m = new Model();
     m->cfg.from_pack(p);
     const ModelCfg& c = m->cfg;

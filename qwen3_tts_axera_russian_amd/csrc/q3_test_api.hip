@@ -473,3 +473,33 @@ extern "C" float q3t_bench_handoff(int n_streams, int blocks, int threads, int n
     }
     return (float)(std::chrono::duration<double, std::micro>(t1 - t0).count() / ((double)iters * n_kernels));
 }
+
+// ---- CPU-side hook: parse weight files the way the loaders do (container, or the reference's .npz /
+// .npy / .safetensors natively) and report what was found.  No GPU call.  Writes up to `cap` bytes of
+// "name dtype ndim d0 d1 d2 d3 fnv1a64-of-bytes\n" lines; returns the tensor count or -1.
+extern "C" int q3t_inspect_weights(const char* path, const char* aux_dir, char* out, int cap) {
+    Pack p;
+    if (!p.open_auto(path, aux_dir)) return -1;
+    std::string s;
+    for (const auto& kv : p.tensors) {
+        const PackTensor& t = kv.second;
+        unsigned long long h = 1469598103934665603ull;
+        for (uint64_t i = 0; i < t.nbytes; i++) h = (h ^ t.data[i]) * 1099511628211ull;
+        char line[256];
+        snprintf(line, sizeof(line), "%s %u %u %llu %llu %llu %llu %llx\n", t.name.c_str(), t.dtype, t.ndim,
+                 (unsigned long long)t.shape[0], (unsigned long long)t.shape[1], (unsigned long long)t.shape[2],
+                 (unsigned long long)t.shape[3], h);
+        s += line;
+    }
+    for (const auto& kv : p.meta) {
+        char line[128];
+        snprintf(line, sizeof(line), "meta %s %.17g\n", kv.first.c_str(), kv.second);
+        s += line;
+    }
+    if (out && cap > 0) {
+        const size_t n = s.size() < (size_t)cap - 1 ? s.size() : (size_t)cap - 1;
+        memcpy(out, s.data(), n);
+        out[n] = 0;
+    }
+    return (int)p.tensors.size();
+}
