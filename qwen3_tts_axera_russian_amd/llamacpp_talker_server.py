@@ -45,8 +45,9 @@ class Qwen3TTSTalkerServer:
         self.sampler = TalkerSampler(self.cfg.codec_eos, self.cfg.cp_vocab, temperature, top_k)
         self.tokenizer = None
         if tokenizer:
-            from transformers import AutoTokenizer  # a LOCAL directory (vocab.json/merges.txt); never a hub name
-            self.tokenizer = AutoTokenizer.from_pretrained(tokenizer, local_files_only=True)
+            # a LOCAL directory (vocab.json / merges.txt of the model snapshot), never a hub name
+            from .tokenizer import ByteLevelBPE
+            self.tokenizer = ByteLevelBPE.from_dir(tokenizer)
         print(f"Loading talker: {model_path}")
         self.llm = LlamaCppModel(model_path, n_ctx=n_ctx, n_threads=n_threads)
         self._running = True
