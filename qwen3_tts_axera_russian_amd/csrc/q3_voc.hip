@@ -248,11 +248,14 @@ struct SplitArgs {
     int n_tiles = 0, tiles_l = 0, tiles_m = 0;
 };
 
-constexpr int STM = 64, STN = 256, SKC = 16;  // workgroup tile and input channels per stage
+constexpr int STN = 256, SKC = 16;  // workgroup tile columns and input channels per k-step
 
-// KT taps; KS 16-channel k-steps per LDS stage (few-tap convs stage several, so a barrier pair buys more MFMAs)
-template <int KT, int KS>
+// KT taps; KS 16-channel k-steps per LDS stage (few-tap convs stage several, so a barrier pair buys more MFMAs);
+// MW 32-row MFMA tiles per workgroup (rows = 32*MW: 96 divides every channel count of the decoder, so the
+// input tile is read by Cout/96 workgroups instead of Cout/64 and no row is padding)
+template <int KT, int KS, int MW>
 __global__ void __launch_bounds__(256, 2) conv_split_kernel(SplitArgs a) {
+    constexpr int STM = 32 * MW;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int halo = (KT - 1) * a.dil;
     const int XW = STN + halo;
@@ -268,9 +271,9 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(SplitArgs a) {
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int lx = tile % a.tiles_l, b = (tile / a.tiles_l) % a.B, my = tile / (a.tiles_l * a.B);
         const int l0 = lx * STN, m0 = my * STM;
-        f16v acc[2][2], accx[2][2];
+        f16v acc[MW][2], accx[MW][2];
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < MW; i++)
 #pragma unroll
             for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -282,7 +285,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(SplitArgs a) {
             __syncthreads();
             // weights: per (k-step, tap) one contiguous 2 KiB run of each plane
             for (int idx = tid; idx < KS * KT * STM * 2; idx += 256) {      // 16-byte pieces
-                const int sk = idx >> 7, rem = idx & 127;      // sk = ks*KT + k
+                const int sk = idx / (STM * 2), rem = idx - sk * (STM * 2);      // sk = ks*KT + k
                 const size_t g = ((size_t)(cb * KT + sk) * a.Mp + m0) * SKC + rem * 8;
                 *(hv8*)(Wh + idx * 8) = *(const hv8*)(a.w_hi + g);
                 *(hv8*)(Wl + idx * 8) = *(const hv8*)(a.w_lo + g);
@@ -305,18 +308,21 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(SplitArgs a) {
             for (int sk = 0; sk < KS * KT; sk++) {
                 const int ks = sk / KT, k = sk % KT;
                 const int off = k * a.dil;   // tap k reads column l - (KT-1-k)*dil = staged column (l-l0) + k*dil
-                hv8 ah[2], al[2], bh[2], bl[2];
+                hv8 ah[MW], al[MW], bh[2], bl[2];
 #pragma unroll
-                for (int i = 0; i < 2; i++) {
+                for (int i = 0; i < MW; i++) {
                     const int row = i * 32 + (lane & 31);
                     ah[i] = *(const hv8*)(Wh + (sk * STM + row) * SKC + (lane >> 5) * 8);
                     al[i] = *(const hv8*)(Wl + (sk * STM + row) * SKC + (lane >> 5) * 8);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
                     const int col = w * 64 + i * 32 + (lane & 31) + off;
                     bh[i] = *(const hv8*)(Xh + ((size_t)(ks * 2 + (lane >> 5)) * XW + col) * 8);
                     bl[i] = *(const hv8*)(Xl + ((size_t)(ks * 2 + (lane >> 5)) * XW + col) * 8);
                 }
 #pragma unroll
-                for (int i = 0; i < 2; i++)
+                for (int i = 0; i < MW; i++)
 #pragma unroll
                     for (int j = 0; j < 2; j++) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
@@ -328,7 +334,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(SplitArgs a) {
         const int Lout = a.Lin * a.stride;
         typedef _Float16 hv4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < MW; i++)
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 const int l = l0 + w * 64 + j * 32 + (lane & 31);
@@ -385,17 +391,18 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(SplitArgs a) {
     }
 }
 
-template <int KT, int KS>
+template <int KT, int KS, int MW>
 static int launch_conv_split_t(hipStream_t s, const SplitArgs& a, int B) {
+    constexpr int STM = 32 * MW;
     if (a.dil > 9) return -1;
     const int halo = (KT - 1) * a.dil;
     const size_t lds = ((size_t)2 * KS * KT * STM * SKC + (size_t)2 * KS * (STN + halo) * SKC) * sizeof(_Float16);
     static bool set_ = false;
     if (!set_) {
-        Q3_HIP(hipFuncSetAttribute((const void*)conv_split_kernel<KT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024), -1);
+        Q3_HIP(hipFuncSetAttribute((const void*)conv_split_kernel<KT, KS, MW>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), -1);
         set_ = true;
     }
-    if (lds > 64 * 1024 || (a.Cin / 16) % KS) return -1;
+    if (lds > 80 * 1024 || (a.Cin / 16) % KS || a.Mp % STM) return -1;   // <= 80 KB: two workgroups per CU
     SplitArgs c = a;
     c.B = B;
     c.tiles_l = (a.Lin + STN - 1) / STN;
@@ -403,20 +410,31 @@ static int launch_conv_split_t(hipStream_t s, const SplitArgs& a, int B) {
     c.n_tiles = c.tiles_l * c.tiles_m * B;
     int grid = c.n_tiles;
     if (g_voc_max_wgs > 0 && grid > g_voc_max_wgs) grid = g_voc_max_wgs;
-    hipLaunchKernelGGL((conv_split_kernel<KT, KS>), dim3(grid), dim3(256), lds, s, c);
+    hipLaunchKernelGGL((conv_split_kernel<KT, KS, MW>), dim3(grid), dim3(256), lds, s, c);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
 }
 
-static int launch_conv_split(hipStream_t s, const SplitArgs& a, int K, int B) {
+template <int MW>
+static int launch_conv_split_m(hipStream_t s, const SplitArgs& a, int K, int B) {
     const int c16 = a.Cin / 16;
     switch (K) {
-        case 1: return c16 % 3 == 0 ? launch_conv_split_t<1, 3>(s, a, B) : c16 % 2 == 0 ? launch_conv_split_t<1, 2>(s, a, B) : launch_conv_split_t<1, 1>(s, a, B);
-        case 2: return c16 % 2 == 0 ? launch_conv_split_t<2, 2>(s, a, B) : launch_conv_split_t<2, 1>(s, a, B);
-        case 3: return c16 % 2 == 0 ? launch_conv_split_t<3, 2>(s, a, B) : launch_conv_split_t<3, 1>(s, a, B);
-        case 7: return launch_conv_split_t<7, 1>(s, a, B);
+        case 1: return c16 % 3 == 0 ? launch_conv_split_t<1, 3, MW>(s, a, B) : c16 % 2 == 0 ? launch_conv_split_t<1, 2, MW>(s, a, B) : launch_conv_split_t<1, 1, MW>(s, a, B);
+        case 2: return c16 % 2 == 0 ? launch_conv_split_t<2, 2, MW>(s, a, B) : launch_conv_split_t<2, 1, MW>(s, a, B);
+        case 3: return c16 % 2 == 0 && MW == 2 ? launch_conv_split_t<3, 2, MW>(s, a, B) : launch_conv_split_t<3, 1, MW>(s, a, B);
+        case 7: return launch_conv_split_t<7, 1, MW>(s, a, B);
         default: return -1;
     }
+}
+
+static int launch_conv_split(hipStream_t s, const SplitArgs& a, int K, int B) {
+    // 96-row tiles where they tile the rows exactly (every channel count of the decoder blocks) and still
+    // give the chip enough workgroups; the 7-tap convs keep 64-row tiles unless 64 would pad (measured:
+    // their 96-row form sits at the register limit and loses 5-15 %)
+    const long tiles96 = (long)((a.Lin + STN - 1) / STN) * (a.M / 96) * B;
+    const bool fits96 = a.M % 96 == 0 && a.Mp % 96 == 0;
+    const bool use96 = fits96 && (a.Mp % 64 != 0 || (tiles96 >= 512 && (K < 7 || a.M % 64 != 0)));
+    return use96 ? launch_conv_split_m<3>(s, a, K, B) : launch_conv_split_m<2>(s, a, K, B);
 }
 
 // Split residual VQ de-quantisation: codes i64 [B][T][NQ] -> y [B][OUT][T].
@@ -652,7 +670,7 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
             if (op.cin % 16 == 0) {   // split-precision copy: [cin/16][tap][Mp128][16] hi / lo fp16
                 const int KTAPS = op.op == VOP_CONV ? op.k : op.k / op.p0;
                 const int Mrows = op.op == VOP_CONV ? op.cout : op.cout * op.p0;
-                const int Mp = (Mrows + 127) / 128 * 128;
+                const int Mp = Mrows % 96 == 0 ? Mrows : (Mrows + 127) / 128 * 128;   // 96- or 64-row tiles, in bounds
                 std::vector<uint16_t> hi((size_t)(op.cin / 16) * KTAPS * Mp * 16, 0), lo(hi.size(), 0);
                 for (int k = 0; k < KTAPS; k++)
                     for (int m = 0; m < Mrows; m++)
