@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--no-vocoder", action="store_true", help="time the talker + code-predictor loop only")
     ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 latency leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-frames", type=int, default=12)
+    ap.add_argument("--cpu-frames", type=int, default=64, help="frames of the CPU baseline sample (~11 s at 6 frames/s)")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--cache", default=os.environ.get("Q3_BENCH_CACHE", "/tmp/q3_bench_cache"))
     return ap.parse_args()
@@ -182,8 +182,9 @@ def dominant_kernel_roofline(lib, rows):
             "algorithmic_bytes_per_launch": int(algo), "avg_launch_us": round(us, 3), "rows": int(rows)}
 
 
-def cpu_baseline(path, cfg, prefix, n_text, pad, frames):
-    """The CPU restatement (oracle/, the 'port' baseline) on a bounded sample of the same workload."""
+def cpu_baseline(path, cfg, prefix, n_text, pad, frames, voc_path=None):
+    """The CPU restatement (oracle/, the 'port' baseline) on a bounded sample of the same workload: one
+    utterance through prefill + `frames` frames (C/OpenMP), then one 64-frame vocoder chunk (torch CPU fp32)."""
     from oracle import oracle as orc
     from oracle.pipeline import CpuPipeline
     from qwen3_tts_axera_russian_amd import weights as W
@@ -194,10 +195,23 @@ def cpu_baseline(path, cfg, prefix, n_text, pad, frames):
     out = pipe.generate(prefix, n_text, pad, frames, ignore_eos=True)
     dt = time.perf_counter() - t0
     assert len(out) == frames
-    return {"value": round(frames / dt, 3), "unit": "codec_frames/s", "cores": threads, "kind": "port",
-            "rtf": round(dt / (frames * FRAME_SEC), 3),
-            "sample": f"1 utterance, prefill {prefix.shape[0]} rows + {frames} frames (talker+code predictor, "
-                      f"fp32 C/OpenMP restatement of the same fp16-weight contract), {dt:.1f}s"}
+    res = {"value": round(frames / dt, 3), "unit": "codec_frames/s", "cores": threads, "kind": "port",
+           "rtf": round(dt / (frames * FRAME_SEC), 3),
+           "sample": f"1 utterance, prefill {prefix.shape[0]} rows + {frames} frames (talker+code predictor, "
+                     f"fp32 C/OpenMP restatement of the same fp16-weight contract), {dt:.1f}s"}
+    if voc_path is not None:
+        from oracle.voc_ref import voc_reference
+        _, vt = W.read_pack(voc_path)
+        codes = np.asarray(out[:64] + [[0] * 16] * max(0, 64 - len(out)), dtype=np.int64)[None]
+        t1 = time.perf_counter()
+        wav = voc_reference(vt, codes)
+        dv = time.perf_counter() - t1
+        assert wav.shape == (1, 64 * 1920)
+        res["vocoder_s_per_chunk"] = round(dv, 2)
+        res["rtf_with_vocoder"] = round((dt / frames * 64 + dv) / (64 * FRAME_SEC), 3)
+        res["value_with_vocoder"] = round(64 / (dt / frames * 64 + dv), 3)
+        res["sample"] += f"; + one 64-frame vocoder chunk (torch CPU fp32, {threads} threads), {dv:.1f}s"
+    return res
 
 
 class Ranks:
@@ -340,7 +354,8 @@ def main():
                          "hbm_frac": round(ab1 / (frame_ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         eng1.destroy()
     if rank == 0 and world == 1 and not a.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(path, cfg, prefixes[0], n_text[0], pad, a.cpu_frames)
+        out["cpu_baseline"] = cpu_baseline(path, cfg, prefixes[0], n_text[0], pad, a.cpu_frames,
+                                           None if a.no_vocoder else make_voc_pack(a.cache, a.seed, rank, barrier))
     if rank == 0:
         print(json.dumps(out), flush=True)
     R.close()

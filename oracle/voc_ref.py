@@ -1,4 +1,5 @@
-"""Independent fp32 reference of the vocoder program (torch CPU ops) -- test infrastructure.
+"""Independent fp32 / float64 reference of the vocoder program (torch CPU ops) -- test infrastructure
+(only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import it).
 Follows the op-table semantics documented in DESIGN.md "Vocoder program"; the decoder's layer
 list itself is not in the reference: parity with the real model is unpinned."""
 import numpy as np

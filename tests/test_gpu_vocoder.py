@@ -13,7 +13,7 @@ from oracle import frontend as fe
 from qwen3_tts_axera_russian_amd import hiplib
 from qwen3_tts_axera_russian_amd import weights as W
 from tests.util import CACHE
-from tests.voc_ref import voc_reference
+from oracle.voc_ref import voc_reference
 
 pytestmark = pytest.mark.gpu
 
