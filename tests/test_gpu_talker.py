@@ -139,3 +139,22 @@ def test_full_depth_28_layers(gpu_lib):
     print("28-layer rel errs:", ["%.2e" % e for e in errs])
     assert max(errs) < 2e-2
     llm.destroy()
+
+
+def test_long_context_beyond_the_reference_n_ctx(gpu_lib, tiny):
+    """BASELINE config 5 (>= 60 s = 750 frames) needs positions past the reference's n_ctx = 512
+    (llamacpp_talker_server.py:104): prefill 600 rows, then decode at positions 600..603 with the
+    attention walking > 512 cached rows, against the oracle."""
+    path, cfg, tensors = tiny
+    n = 600
+    llm = LlamaCppModel(path, n_ctx=640)
+    ref = orc.TalkerOracle(cfg, tensors, n_ctx=640)
+    rng = np.random.default_rng(11)
+    prefix = _prefix(rng, n)
+    errs = [rel_err(llm.get_hidden(prefix, keep_history=0), ref.forward(prefix, 0))]
+    for step in range(4):
+        fb = _prefix(rng, 1)
+        errs.append(rel_err(llm.get_hidden(fb, keep_history=1), ref.forward(fb, n + step)))
+    print("long-context rel errs:", ["%.2e" % e for e in errs])
+    assert max(errs) < TOL and llm.pos == n + 4
+    llm.destroy()

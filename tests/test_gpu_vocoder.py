@@ -119,3 +119,26 @@ def test_synthesize_chunk_walk_and_int16(gpu_lib, tiny_voc):
         np.testing.assert_array_equal(v.synth_i16(codes), fe.to_int16(want))
     assert len(v.synth_f32(np.zeros((150, 16), np.int64))) == 156 * 1920
     v.close()
+
+
+def test_full_size_table_is_causal_and_deterministic(gpu_lib, tmp_path_factory):
+    """Size-independent properties at the full default table (307 GFLOP per 64-frame chunk, the bench's
+    vocoder): every convolution is causal, so the first 48 frames' samples must not change -- bit for bit --
+    when the last 16 frames' codes do (what chunked streaming with overlap relies on, vocoder_server.py:84-117);
+    a chunk decodes to the same samples alone and inside a batch; and twice the same input gives the same bits."""
+    path = os.path.join(CACHE, "voc_full_s1234.q3w")
+    if not os.path.exists(path):
+        W.write_pack(path, {"voc_chunk": 64.0}, W.make_synthetic_voc(W.VocConfig(), seed=1234))
+    v = Voc(gpu_lib, path, max_batch=3)
+    rng = np.random.default_rng(9)
+    a = rng.integers(0, 2048, size=(64, 16)).astype(np.int64)
+    b = a.copy()
+    b[48:] = rng.integers(0, 2048, size=(16, 16))
+    c = rng.integers(0, 2048, size=(64, 16)).astype(np.int64)
+    out = v.decode(np.stack([a, b, c])).copy()
+    assert np.abs(out).max() > 0.01 and np.isfinite(out).all()
+    np.testing.assert_array_equal(out[0, :48 * 1920], out[1, :48 * 1920])
+    assert not np.array_equal(out[0, 48 * 1920:], out[1, 48 * 1920:])
+    np.testing.assert_array_equal(v.decode(a[None])[0], out[0])          # alone == inside a batch
+    np.testing.assert_array_equal(v.decode(np.stack([a, b, c])), out)    # deterministic
+    v.close()
