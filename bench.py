@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--no-vocoder", action="store_true", help="time the talker + code-predictor loop only")
     ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 latency leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-frames", type=int, default=64, help="frames of the CPU baseline sample (~11 s at 6 frames/s)")
+    ap.add_argument("--cpu-frames", type=int, default=96, help="frames of the CPU baseline sample (~12 s at 8 frames/s)")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--cache", default=os.environ.get("Q3_BENCH_CACHE", "/tmp/q3_bench_cache"))
     return ap.parse_args()
