@@ -256,6 +256,7 @@ constexpr int STN = 256, SKC = 16;  // workgroup tile columns and input channels
 template <int KT, int KS, int MW>
 __global__ void __launch_bounds__(256, 2) conv_split_kernel(SplitArgs a) {
     constexpr int STM = 32 * MW;
+    constexpr int UNR = (MW == 3 && KT == 7) ? 1 : KS * KT;   // unroll of the tap loop
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int halo = (KT - 1) * a.dil;
     const int XW = STN + halo;
@@ -304,7 +305,8 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(SplitArgs a) {
                 *(hv8*)(Xl + idx * 8) = vl;
             }
             __syncthreads();
-#pragma unroll
+            // the 96-row 7-tap form sits at the 256-register limit: walking its taps one at a time keeps it from spilling
+#pragma unroll UNR
             for (int sk = 0; sk < KS * KT; sk++) {
                 const int ks = sk / KT, k = sk % KT;
                 const int off = k * a.dil;   // tap k reads column l - (KT-1-k)*dil = staged column (l-l0) + k*dil
@@ -429,11 +431,10 @@ static int launch_conv_split_m(hipStream_t s, const SplitArgs& a, int K, int B) 
 
 static int launch_conv_split(hipStream_t s, const SplitArgs& a, int K, int B) {
     // 96-row tiles where they tile the rows exactly (every channel count of the decoder blocks) and still
-    // give the chip enough workgroups; the 7-tap convs keep 64-row tiles unless 64 would pad (measured:
-    // their 96-row form sits at the register limit and loses 5-15 %)
+    // give the chip enough workgroups: the input tile is read by Cout/96 workgroups instead of Cout/64
     const long tiles96 = (long)((a.Lin + STN - 1) / STN) * (a.M / 96) * B;
     const bool fits96 = a.M % 96 == 0 && a.Mp % 96 == 0;
-    const bool use96 = fits96 && (a.Mp % 64 != 0 || (tiles96 >= 512 && (K < 7 || a.M % 64 != 0)));
+    const bool use96 = fits96 && (a.Mp % 64 != 0 || tiles96 >= 512);
     return use96 ? launch_conv_split_m<3>(s, a, K, B) : launch_conv_split_m<2>(s, a, K, B);
 }
 
