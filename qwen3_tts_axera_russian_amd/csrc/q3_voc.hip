@@ -246,6 +246,7 @@ struct SplitArgs {
     const float* oinv_beta = nullptr;
     int Cin = 0, M = 0, Mp = 0, dil = 1, Lin = 0, stride = 1, Cout = 0, clamp = 0, B = 0;
     int n_tiles = 0, tiles_l = 0, tiles_m = 0;
+    int my_fast = 0;   // tile order, see conv_split_kernel
 };
 
 constexpr int STN = 256, SKC = 16;  // workgroup tile columns and input channels per k-step
@@ -267,10 +268,25 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(SplitArgs a) {
     _Float16* Xl = Xh + (size_t)KS * XW * SKC;
     const int C16 = a.Cin >> 4;
     const hv8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    // tiles: columns fastest, then chunk, row tile slowest -- at any moment the chip works on one or two row
-    // tiles, whose weights stay in every XCD's L2 while the input tiles stream
+    // Tile order.  Big weights (my_fast = 0): columns fastest, then chunk, row tile slowest -- at any moment the
+    // chip works on one or two row tiles, whose weights stay in every XCD's L2 while the input tiles stream.
+    // Small weights (my_fast = 1, they fit every L2 whole): XCD x (= workgroup id mod 8 under round-robin
+    // placement) owns the column tiles x, x+8, ... and walks each one's row tiles back to back, so the input
+    // tile comes from HBM once and from that XCD's L2 for the other row tiles.
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        const int lx = tile % a.tiles_l, b = (tile / a.tiles_l) % a.B, my = tile / (a.tiles_l * a.B);
+        int lx, b, my;
+        if (a.my_fast) {
+            const int xcd = tile & 7, j = tile >> 3;
+            my = j % a.tiles_m;
+            const int cg = (j / a.tiles_m) * 8 + xcd;
+            if (cg >= a.tiles_l * a.B) continue;
+            lx = cg % a.tiles_l;
+            b = cg / a.tiles_l;
+        } else {
+            lx = tile % a.tiles_l;
+            b = (tile / a.tiles_l) % a.B;
+            my = tile / (a.tiles_l * a.B);
+        }
         const int l0 = lx * STN, m0 = my * STM;
         f16v acc[MW][2], accx[MW][2];
 #pragma unroll
@@ -410,6 +426,9 @@ static int launch_conv_split_t(hipStream_t s, const SplitArgs& a, int B) {
     c.tiles_l = (a.Lin + STN - 1) / STN;
     c.tiles_m = (a.M + STM - 1) / STM;
     c.n_tiles = c.tiles_l * c.tiles_m * B;
+    // both planes of all taps of the weights: small enough to live in every XCD's 4 MiB L2 beside the stream?
+    c.my_fast = c.tiles_m > 1 && (size_t)a.Cin * a.Mp * KT * 4 <= (size_t)2 << 20;
+    if (c.my_fast) c.n_tiles = (c.tiles_l * B + 7) / 8 * 8 * c.tiles_m;
     int grid = c.n_tiles;
     if (g_voc_max_wgs > 0 && grid > g_voc_max_wgs) grid = g_voc_max_wgs;
     hipLaunchKernelGGL((conv_split_kernel<KT, KS, MW>), dim3(grid), dim3(256), lds, s, c);
