@@ -41,6 +41,8 @@ def voc_reference(tensors: dict, codes: np.ndarray, n_ops: int = -1, dtype=np.fl
                 if flags & W.VF_RES_SAVE:
                     res = x
                 h = _snake(x, t(p + "alpha"), t(p + "beta")) if flags & W.VF_SNAKE else x
+                if flags & W.VF_GELU:
+                    h = F.gelu(h)     # exact (erf) form
                 bias = t(p + "bias") if (p + "bias") in tensors else None
                 if op == W.VOP_CONV:
                     y = F.conv1d(F.pad(h, ((k - 1) * p0, 0)), t(p + "weight"), bias, dilation=p0)
@@ -51,6 +53,41 @@ def voc_reference(tensors: dict, codes: np.ndarray, n_ops: int = -1, dtype=np.fl
                 if flags & W.VF_CLAMP:
                     y = y.clamp(-1.0, 1.0)
                 x = y
+            elif op == W.VOP_DWCONV:   # causal depthwise conv (ConvNeXt)
+                k, flags = int(row[3]), int(row[5])
+                if flags & W.VF_RES_SAVE:
+                    res = x
+                x = F.conv1d(F.pad(x, (k - 1, 0)), t(p + "weight"), t(p + "bias"), groups=x.shape[1])
+            elif op == W.VOP_NORM:     # over channels, per column: 0 RMSNorm, 1 LayerNorm
+                kind, eps, flags = int(row[3]), int(row[4]) * 1e-9, int(row[5])
+                if flags & W.VF_RES_SAVE:
+                    res = x
+                w = t(p + "weight")[None, :, None]
+                if kind == 0:
+                    x = x * torch.rsqrt((x * x).mean(1, keepdim=True) + eps) * w
+                else:
+                    mu = x.mean(1, keepdim=True)
+                    var = ((x - mu) ** 2).mean(1, keepdim=True)
+                    x = (x - mu) * torch.rsqrt(var + eps) * w + t(p + "bias")[None, :, None]
+            elif op == W.VOP_ATTN:     # [q | k | v] head-major channels -> causal sliding-window attention with RoPE
+                nh, hd, window, theta = int(row[3]), int(row[4]), int(row[6]), float(row[7])
+                B, _, L = x.shape
+                q, k_, v = [z.reshape(B, nh, hd, L).transpose(2, 3) for z in x.split(nh * hd, dim=1)]   # [B,nh,L,hd]
+                pos = torch.arange(L, dtype=x.dtype)
+                inv = theta ** (-torch.arange(0, hd, 2, dtype=x.dtype) / hd)
+                ang = pos[:, None] * inv[None, :]
+                cos, sin = torch.cat([ang.cos(), ang.cos()], -1), torch.cat([ang.sin(), ang.sin()], -1)
+                rot = lambda z: torch.cat([-z[..., hd // 2:], z[..., : hd // 2]], -1)
+                q, k_ = q * cos + rot(q) * sin, k_ * cos + rot(k_) * sin
+                sc = (q @ k_.transpose(2, 3)) / (hd ** 0.5)
+                i, j = torch.arange(L)[:, None], torch.arange(L)[None, :]
+                sc = sc.masked_fill(~((j <= i) & (j > i - window)), float("-inf"))
+                o = torch.softmax(sc, -1) @ v                                   # [B,nh,L,hd]
+                x = o.transpose(2, 3).reshape(B, nh * hd, L)
+            elif op == W.VOP_GLU:      # act(first half) * second half; 0 SiLU, 1 GELU
+                c, act = int(row[2]), int(row[3])
+                g, u = x[:, :c], x[:, c:]
+                x = (F.silu(g) if act == 0 else F.gelu(g)) * u
             else:
                 raise ValueError(f"unknown vocoder op {op}")
     return x.numpy() if n_ops >= 0 else x[:, 0, :].numpy()

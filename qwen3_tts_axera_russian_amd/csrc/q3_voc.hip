@@ -22,8 +22,10 @@ namespace q3 {
 
 typedef float f16v __attribute__((ext_vector_type(16)));
 
-enum { VOP_RVQ = 1, VOP_CONV = 2, VOP_CONVT = 3 };
-enum { VF_SNAKE = 1, VF_RES_ADD = 2, VF_RES_SAVE = 4, VF_CLAMP = 8 };
+enum { VOP_RVQ = 1, VOP_CONV = 2, VOP_CONVT = 3, VOP_DWCONV = 4, VOP_NORM = 5, VOP_ATTN = 6, VOP_GLU = 7 };
+enum { VF_SNAKE = 1, VF_RES_ADD = 2, VF_RES_SAVE = 4, VF_CLAMP = 8, VF_GELU = 16 };
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
 struct ConvArgs {
     const float* x = nullptr;   // [B][Cin][Lin]
@@ -34,6 +36,7 @@ struct ConvArgs {
     const float* alpha = nullptr;     // [Cin] Snake: x + inv_beta * sin^2(alpha x), applied to the input
     const float* inv_beta = nullptr;
     const float* res = nullptr;       // [B][Cout][L] added in the epilogue
+    int gelu = 0;                     // exact GELU applied to the input (ConvNeXt's second pointwise conv)
     int Cin = 0, M = 0, K = 0, dil = 1, Lin = 0, stride = 1, Cout = 0, clamp = 0;
     int n_tiles = 0, tiles_l = 0, tiles_m = 0;  // set by the launcher
 };
@@ -90,6 +93,7 @@ __global__ void __launch_bounds__(256) conv_kernel(ConvArgs a) {
                         const float sn = __sinf(a.alpha[ci0 + ci] * v);
                         v = v + a.inv_beta[ci0 + ci] * (sn * sn);
                     }
+                    if (a.gelu) v = gelu_erf(v);
                 }
                 Xs[idx] = v;
             }
@@ -204,7 +208,7 @@ typedef _Float16 hv8 __attribute__((ext_vector_type(8)));
 
 __global__ void __launch_bounds__(256) snake_split_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
                                                           const float* __restrict__ inv_beta, _Float16* __restrict__ xh,
-                                                          _Float16* __restrict__ xl, int C, int L) {
+                                                          _Float16* __restrict__ xl, int C, int L, int gelu) {
     const int l = blockIdx.x * 256 + threadIdx.x, cg = blockIdx.y, b = blockIdx.z;   // cg: 8-channel group
     if (l >= L) return;
     const float* xp = x + ((size_t)b * C + cg * 8) * L + l;
@@ -217,6 +221,10 @@ __global__ void __launch_bounds__(256) snake_split_kernel(const float* __restric
             const float sn = __sinf(alpha[cg * 8 + j] * v[j]);
             v[j] = v[j] + inv_beta[cg * 8 + j] * (sn * sn);
         }
+    }
+    if (gelu) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = gelu_erf(v[j]);
     }
     hv8 h, lo;
 #pragma unroll
@@ -244,6 +252,7 @@ struct SplitArgs {
     _Float16* ol = nullptr;
     const float* oalpha = nullptr;
     const float* oinv_beta = nullptr;
+    int ogelu = 0;
     int Cin = 0, M = 0, Mp = 0, dil = 1, Lin = 0, stride = 1, Cout = 0, clamp = 0, B = 0;
     int n_tiles = 0, tiles_l = 0, tiles_m = 0;
     int my_fast = 0;   // tile order, see conv_split_kernel
@@ -395,6 +404,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(SplitArgs a) {
                                     const float sn = __sinf(a.oalpha[mg + q] * t);
                                     t = t + a.oinv_beta[mg + q] * (sn * sn);
                                 }
+                                if (a.ogelu) t = gelu_erf(t);
                                 const _Float16 hi = (_Float16)fminf(fmaxf(t, -65504.f), 65504.f);
                                 vh[q] = hi;
                                 vl[q] = (_Float16)((t - (float)hi) * 2048.0f);
@@ -457,6 +467,109 @@ static int launch_conv_split(hipStream_t s, const SplitArgs& a, int K, int B) {
     return use96 ? launch_conv_split_m<3>(s, a, K, B) : launch_conv_split_m<2>(s, a, K, B);
 }
 
+// ---------------------------------------------------------------------------
+// The small f32 ops of the published decoder's transformer / ConvNeXt stages (activations [B][C][L], L <= a few
+// hundred columns: latency-sized kernels, one thread per output or per column).
+// ---------------------------------------------------------------------------
+// causal depthwise conv: y[c][l] = bias[c] + sum_k w[c][k] * x[c][l - (K-1-k)]
+__global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ y, int C, int L, int K) {
+    const int l = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (l >= L) return;
+    const float* xr = x + ((size_t)b * C + c) * L;
+    float acc = bias ? bias[c] : 0.f;
+    for (int k = 0; k < K; k++) {
+        const int ls = l - (K - 1 - k);
+        if (ls >= 0) acc += w[c * K + k] * xr[ls];
+    }
+    y[((size_t)b * C + c) * L + l] = acc;
+}
+
+// RMSNorm (kind 0) / LayerNorm (kind 1) over the channels of every column
+__global__ void __launch_bounds__(256) chan_norm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int C, int L,
+                                                        int kind, float eps) {
+    const int l = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (l >= L) return;
+    const float* xc = x + (size_t)b * C * L + l;
+    float mu = 0.f;
+    if (kind == 1) {
+        for (int c = 0; c < C; c++) mu += xc[(size_t)c * L];
+        mu /= (float)C;
+    }
+    float ss = 0.f;
+    for (int c = 0; c < C; c++) {
+        const float d = xc[(size_t)c * L] - mu;
+        ss += d * d;
+    }
+    const float inv = 1.0f / sqrtf(ss / (float)C + eps);
+    float* yc = y + (size_t)b * C * L + l;
+    for (int c = 0; c < C; c++) {
+        float v = (xc[(size_t)c * L] - mu) * inv * w[c];
+        if (bias) v += bias[c];
+        yc[(size_t)c * L] = v;
+    }
+}
+
+// x = [q | k | v] (head-major channels, [3*H*D][L]) -> causal sliding-window attention with rotate-half RoPE
+// (positions = columns of the chunk).  One wave per (query column, head); lane j owns the pair (j, j + D/2).
+__global__ void __launch_bounds__(64) voc_attn_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int D, int L,
+                                                      int window, float theta) {
+    const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z, j = threadIdx.x;
+    const int half = D / 2, HD = H * D;
+    const bool on = j < half;
+    const float* xb = x + (size_t)b * 3 * HD * L;
+    const float inv_freq = on ? __powf(theta, -2.0f * (float)j / (float)D) : 0.f;
+    auto rope = [&](const float* base, int pos, float& a, float& c) {   // rows (j, j+half) of a head at column pos
+        float x0 = 0.f, x1 = 0.f;
+        if (on) {
+            x0 = base[(size_t)j * L + pos];
+            x1 = base[(size_t)(j + half) * L + pos];
+        }
+        float sn, cs;
+        __sincosf((float)pos * inv_freq, &sn, &cs);
+        a = x0 * cs - x1 * sn;
+        c = x1 * cs + x0 * sn;
+    };
+    float q0, q1;
+    rope(xb + (size_t)(h * D) * L, i, q0, q1);
+    const float scale = 1.0f / sqrtf((float)D);
+    float m = -INFINITY, lsum = 0.f, o0 = 0.f, o1 = 0.f;
+    const int t0 = i - window + 1 > 0 ? i - window + 1 : 0;
+    for (int t = t0; t <= i; t++) {
+        float k0, k1;
+        rope(xb + (size_t)(HD + h * D) * L, t, k0, k1);
+        float sc = q0 * k0 + q1 * k1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sc += __shfl_xor(sc, o, 64);
+        sc *= scale;
+        const float mn = fmaxf(m, sc), corr = __expf(m - mn), p = __expf(sc - mn);
+        float v0 = 0.f, v1 = 0.f;
+        if (on) {
+            const float* vb = xb + (size_t)(2 * HD + h * D) * L;
+            v0 = vb[(size_t)j * L + t];
+            v1 = vb[(size_t)(j + half) * L + t];
+        }
+        lsum = lsum * corr + p;
+        o0 = o0 * corr + p * v0;
+        o1 = o1 * corr + p * v1;
+        m = mn;
+    }
+    if (on) {
+        float* yb = y + ((size_t)b * HD + h * D) * L;
+        yb[(size_t)j * L + i] = o0 / lsum;
+        yb[(size_t)(j + half) * L + i] = o1 / lsum;
+    }
+}
+
+// y[c][l] = act(x[c][l]) * x[C + c][l]; act 0 SiLU, 1 GELU
+__global__ void __launch_bounds__(256) glu_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int L, int act) {
+    const int l = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (l >= L) return;
+    const float g = x[((size_t)b * 2 * C + c) * L + l], u = x[((size_t)b * 2 * C + C + c) * L + l];
+    y[((size_t)b * C + c) * L + l] = (act == 0 ? g / (1.0f + __expf(-g)) : gelu_erf(g)) * u;
+}
+
 // Split residual VQ de-quantisation: codes i64 [B][T][NQ] -> y [B][OUT][T].
 // Quantiser 0 (semantic) and 1..NQ-1 (acoustic) each sum their codebook rows ([NQ][CB][DIM]) and go
 // through their own DIM->OUT projection (1x1 conv without bias); the two results add.
@@ -489,6 +602,8 @@ __global__ void __launch_bounds__(256) rvq_kernel(const int64_t* __restrict__ co
 struct VocOp {
     int op = 0, cin = 0, cout = 0, k = 0, p0 = 0, flags = 0, nq = 0, cb = 0;
     float *w = nullptr, *bias = nullptr, *alpha = nullptr, *inv_beta = nullptr;  // device
+    int kind = 0, heads = 0, head_dim = 0, window = 0;   // NORM kind; ATTN geometry
+    float eps = 0.f, theta = 10000.f;
     _Float16 *w_hi = nullptr, *w_lo = nullptr;  // split-precision weights (null: exact path only)
     int Mp128 = 0;
     float *p_sem = nullptr, *p_ac = nullptr;
@@ -752,6 +867,65 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
             flops += 2.0 * op.cin * op.cout * op.k * L;  // per input column; convT: k taps spread over s outputs
             C = op.cout;
             if (op.op == VOP_CONVT) L *= op.p0;
+        } else if (op.op == VOP_DWCONV || op.op == VOP_NORM || op.op == VOP_ATTN || op.op == VOP_GLU) {
+            op.cin = r[1];
+            op.cout = r[2];
+            op.flags = r[5];
+            if (op.cin != C) {
+                Q3_LOG("vocoder op %d: expects %d input channels, previous op produced %d", i, op.cin, C);
+                ok = false;
+                break;
+            }
+            auto vec = [&](const char* n, uint64_t ne, bool required) -> float* {
+                const PackTensor* t = p.find(base + n);
+                if (!t) {
+                    if (required) {
+                        Q3_LOG("vocoder program op %d needs tensor %s%s", i, base.c_str(), n);
+                        ok = false;
+                    }
+                    return nullptr;
+                }
+                if (t->numel() != ne) {
+                    Q3_LOG("vocoder op %d: tensor %s has %llu elements, the program needs %llu", i, n,
+                           (unsigned long long)t->numel(), (unsigned long long)ne);
+                    ok = false;
+                    return nullptr;
+                }
+                float* d = voc_up(v, t);
+                if (!d) ok = false;
+                return d;
+            };
+            if (op.op == VOP_DWCONV) {          // torch depthwise Conv1d weight [C][1][k]
+                op.k = r[3];
+                if (op.cout != op.cin || op.k < 1 || op.k > 64) ok = false;
+                op.w = vec("weight", (uint64_t)op.cin * op.k, true);
+                op.bias = vec("bias", (uint64_t)op.cin, false);
+                flops += 2.0 * op.cin * op.k * L;
+            } else if (op.op == VOP_NORM) {
+                op.kind = r[3];
+                op.eps = (float)((double)r[4] * 1e-9);
+                if (op.cout != op.cin || (op.kind != 0 && op.kind != 1)) ok = false;
+                op.w = vec("weight", (uint64_t)op.cin, true);
+                op.bias = vec("bias", (uint64_t)op.cin, false);
+            } else if (op.op == VOP_ATTN) {
+                op.heads = r[3];
+                op.head_dim = r[4];
+                op.window = r[6];
+                op.theta = (float)r[7];
+                if (op.heads <= 0 || op.head_dim <= 0 || op.head_dim > 128 || (op.head_dim & 1) || op.window <= 0 ||
+                    op.cin != 3 * op.heads * op.head_dim || op.cout != op.heads * op.head_dim)
+                    ok = false;
+                flops += 4.0 * op.heads * op.head_dim * (double)(op.window < L ? op.window : L) * L;
+            } else {
+                op.kind = r[3];   // 0 SiLU, 1 GELU
+                if (op.cin != 2 * op.cout || (op.kind != 0 && op.kind != 1)) ok = false;
+            }
+            if (!ok) {
+                Q3_LOG("vocoder op %d: malformed program row / tensors", i);
+                break;
+            }
+            C = op.cout;
+            if ((size_t)op.cin * L > max_elems) max_elems = (size_t)op.cin * L;
         } else {
             Q3_LOG("vocoder program op %d: unknown opcode %d", i, op.op);
             ok = false;
@@ -816,7 +990,8 @@ static int voc_conv_split(Voc* v, const VocOp& op, const VocOp* next, bool last,
         if (!st.f32_cur) return -1;
         in_set = 0;
         hipLaunchKernelGGL(snake_split_kernel, dim3((unsigned)((L + 255) / 256), op.cin / 8, B), dim3(256), 0, v->s,
-                           v->buf[st.f32_idx], op.alpha, op.inv_beta, v->plane[0], v->plane[1], op.cin, (int)L);
+                           v->buf[st.f32_idx], op.alpha, op.inv_beta, v->plane[0], v->plane[1], op.cin, (int)L,
+                           (op.flags & VF_GELU) ? 1 : 0);
         Q3_HIP(hipGetLastError(), -1);
     }
     if (op.flags & VF_RES_SAVE) {
@@ -860,6 +1035,7 @@ static int voc_conv_split(Voc* v, const VocOp& op, const VocOp* next, bool last,
             sa.oalpha = next->alpha;
             sa.oinv_beta = next->inv_beta;
         }
+        sa.ogelu = (next->flags & VF_GELU) ? 1 : 0;
     }
     if (launch_conv_split(v->s, sa, KT, B)) return -1;
     if (want_f32) {
@@ -895,6 +1071,33 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
             st.f32_idx = cur;
             st.f32_cur = true;
             st.planes = -1;
+        } else if (op.op == VOP_DWCONV || op.op == VOP_NORM || op.op == VOP_ATTN || op.op == VOP_GLU) {
+            if (!st.f32_cur) return -1;   // these ops read the f32 activation (their producer wrote one: they are no conv)
+            cur = st.f32_idx;
+            in = v->buf[cur];
+            out = v->buf[cur ^ 1];
+            if (op.flags & VF_RES_SAVE) {
+                Q3_HIP(hipMemcpyAsync(v->buf[2], in, sizeof(float) * (size_t)B * C * L, hipMemcpyDeviceToDevice, v->s), -1);
+                res = v->buf[2];
+                st.res = res;
+            }
+            const unsigned lb = (unsigned)((L + 255) / 256);
+            if (op.op == VOP_DWCONV)
+                hipLaunchKernelGGL(dwconv_kernel, dim3(lb, op.cin, B), dim3(256), 0, v->s, in, op.w, op.bias, out, op.cin, (int)L, op.k);
+            else if (op.op == VOP_NORM)
+                hipLaunchKernelGGL(chan_norm_kernel, dim3(lb, B), dim3(256), 0, v->s, in, op.w, op.bias, out, op.cin, (int)L,
+                                   op.kind, op.eps);
+            else if (op.op == VOP_ATTN)
+                hipLaunchKernelGGL(voc_attn_kernel, dim3((unsigned)L, op.heads, B), dim3(64), 0, v->s, in, out, op.heads,
+                                   op.head_dim, (int)L, op.window, op.theta);
+            else
+                hipLaunchKernelGGL(glu_kernel, dim3(lb, op.cout, B), dim3(256), 0, v->s, in, out, op.cout, (int)L, op.kind);
+            Q3_HIP(hipGetLastError(), -1);
+            C = op.cout;
+            cur ^= 1;
+            st.f32_idx = cur;
+            st.f32_cur = true;
+            st.planes = -1;
         } else if (g_voc_split && op.w_hi) {
             const bool last = i + 1 == nrun;
             const VocOp* next = (i + 1 < v->ops.size()) ? &v->ops[i + 1] : nullptr;
@@ -921,6 +1124,7 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
             a.Cout = op.cout;
             a.Lin = (int)L;
             a.clamp = (op.flags & VF_CLAMP) ? 1 : 0;
+            a.gelu = (op.flags & VF_GELU) ? 1 : 0;
             if (op.op == VOP_CONV) {
                 a.K = op.k;
                 a.dil = op.p0;

@@ -332,7 +332,8 @@ def from_hf_checkpoint(model_dir: str, out_path: str, cfg: ModelConfig | None = 
 # vocoder program (include/qwen3tts_voc.h, csrc/q3_voc.hip)
 # ----------------------------------------------------------------------------
 VOP_RVQ, VOP_CONV, VOP_CONVT = 1, 2, 3
-VF_SNAKE, VF_RES_ADD, VF_RES_SAVE, VF_CLAMP = 1, 2, 4, 8
+VOP_DWCONV, VOP_NORM, VOP_ATTN, VOP_GLU = 4, 5, 6, 7
+VF_SNAKE, VF_RES_ADD, VF_RES_SAVE, VF_CLAMP, VF_GELU = 1, 2, 4, 8, 16
 
 
 @dataclass
@@ -342,8 +343,12 @@ class VocConfig:
     16 codebooks x 2048 entries (split RVQ: 1 semantic + 15 acoustic, dim 256 -> 512), causal conv
     to the latent width, two x2 transposed-conv upsamplers, then a BigVGAN-style stack with rates
     8,5,4,3 (2*2*8*5*4*3 = 1920 samples per frame) whose residual units use dilations 1,3,9 and
-    Snake activations.  The pre-transformer and the ConvNeXt blocks of the published model are not
-    in this table yet ("Vocoder program")."""
+    Snake activations.  `pre_transformer_layers` > 0 inserts the published model's sliding-window
+    transformer (input/output projections, pre-norm layers: RMSNorm -> q/k/v -> RoPE attention -> o ->
+    residual, RMSNorm -> gated MLP -> residual; layer scales fold into the o / down weights at
+    conversion) after the first conv, `convnext` a ConvNeXt block (depthwise k7 -> LayerNorm -> 4x
+    pointwise -> GELU -> pointwise -> residual) after each x2 upsampler.  Both default off: their
+    hyper-parameters are recollection, not reference ("Vocoder program")."""
     n_q: int = 16
     codebook_size: int = 2048
     codebook_dim: int = 256
@@ -355,10 +360,27 @@ class VocConfig:
     rates: tuple = (8, 5, 4, 3)
     dilations: tuple = (1, 3, 9)
     kernel: int = 7
+    pre_transformer_layers: int = 0
+    tf_hidden: int = 512
+    tf_heads: int = 16
+    tf_head_dim: int = 64
+    tf_ffn: int = 1024
+    tf_window: int = 72
+    tf_rope_theta: int = 10000
+    tf_eps_e9: int = 10000        # 1e-5
+    convnext: bool = False
+    convnext_kernel: int = 7
+    convnext_eps_e9: int = 1000   # 1e-6
 
 
 def tiny_voc_config() -> VocConfig:
     return VocConfig(codebook_dim=32, rvq_out=64, latent=64, decoder_dim=128)
+
+
+def tiny_full_voc_config() -> VocConfig:
+    """Every op kind of the program at test size: transformer (window shorter than the chunk) + ConvNeXt."""
+    return VocConfig(codebook_dim=32, rvq_out=64, latent=64, decoder_dim=128, pre_transformer_layers=2, tf_hidden=64,
+                     tf_heads=4, tf_head_dim=16, tf_ffn=96, tf_window=24, convnext=True)
 
 
 def voc_program(vc: VocConfig):
@@ -387,9 +409,41 @@ def voc_program(vc: VocConfig):
             t.update({"alpha": (cin,), "beta": (cin,)})
         add([VOP_CONVT, cin, cout, k, stride, flags], t)
 
+    def linear(cin, cout, flags, bias=True):
+        t = {"weight": (cout, cin, 1)}
+        if bias:
+            t["bias"] = (cout,)
+        add([VOP_CONV, cin, cout, 1, 1, flags], t)
+
+    def norm(c, kind, eps_e9, flags):
+        t = {"weight": (c,)}
+        if kind == 1:
+            t["bias"] = (c,)
+        add([VOP_NORM, c, c, kind, eps_e9, flags], t)
+
     conv(vc.rvq_out, vc.latent, vc.pre_kernel, 1, 0)
+    if vc.pre_transformer_layers > 0:
+        H, nh, hd, F = vc.tf_hidden, vc.tf_heads, vc.tf_head_dim, vc.tf_ffn
+        linear(vc.latent, H, 0)                                          # input projection
+        for _ in range(vc.pre_transformer_layers):
+            norm(H, 0, vc.tf_eps_e9, VF_RES_SAVE)
+            linear(H, 3 * nh * hd, 0, bias=False)                        # q | k | v, head-major
+            add([VOP_ATTN, 3 * nh * hd, nh * hd, nh, hd, 0, vc.tf_window, vc.tf_rope_theta], {})
+            linear(nh * hd, H, VF_RES_ADD, bias=False)                   # o projection (x layer scale)
+            norm(H, 0, vc.tf_eps_e9, VF_RES_SAVE)
+            linear(H, 2 * F, 0, bias=False)                              # gate | up
+            add([VOP_GLU, 2 * F, F, 0], {})                              # silu(gate) * up
+            linear(F, H, VF_RES_ADD, bias=False)                         # down projection (x layer scale)
+        norm(H, 0, vc.tf_eps_e9, 0)
+        linear(H, vc.latent, 0)                                          # output projection
     for f in vc.upsample_ratios:
         convt(vc.latent, vc.latent, f, f, 0)
+        if vc.convnext:
+            c = vc.latent
+            add([VOP_DWCONV, c, c, vc.convnext_kernel, 1, VF_RES_SAVE], {"weight": (c, 1, vc.convnext_kernel), "bias": (c,)})
+            norm(c, 1, vc.convnext_eps_e9, 0)
+            linear(c, 4 * c, 0)
+            linear(4 * c, c, VF_GELU | VF_RES_ADD)                       # (x layer scale)
     conv(vc.latent, vc.decoder_dim, vc.kernel, 1, 0)
     c = vc.decoder_dim
     for r in vc.rates:
@@ -407,7 +461,11 @@ def make_synthetic_voc(vc: VocConfig, seed: int = 1234) -> dict:
     t = {"voc.program": np.asarray(prog, dtype=np.int32)}
     for n, shp in shapes.items():
         rng = _rng_for(n, seed)
-        if n.endswith(("alpha", "beta")):
+        row = prog[int(n.split(".")[1][2:])]
+        if row[0] == VOP_NORM:
+            a = (1.0 + 0.1 * rng.standard_normal(shp, dtype=np.float32)) if n.endswith("weight") else \
+                0.05 * rng.standard_normal(shp, dtype=np.float32)
+        elif n.endswith(("alpha", "beta")):
             a = 0.3 * rng.standard_normal(shp, dtype=np.float32)
         elif n.endswith("bias"):
             a = 0.02 * rng.standard_normal(shp, dtype=np.float32)
@@ -421,6 +479,8 @@ def make_synthetic_voc(vc: VocConfig, seed: int = 1234) -> dict:
             # the 1x1 conv that closes a residual unit is damped further
             row = prog[int(n.split(".")[1][2:])]
             gain = 0.25 if (".weight" in n and row[0] == VOP_CONV and row[3] == 1 and (row[5] & VF_RES_ADD)) else 0.7
+            if row[0] == VOP_CONV and row[3] == 1 and not (row[5] & (VF_RES_ADD | VF_SNAKE)):
+                gain = 1.0   # plain projections (transformer q/k/v, gate/up, ConvNeXt expansion) keep the scale
             a = (gain * rng.standard_normal(shp, dtype=np.float32) / np.sqrt(fan_in)).astype(np.float32)
         t[n] = a.astype(np.float32)
     return t
