@@ -252,7 +252,6 @@ struct SplitArgs {
     _Float16* ol = nullptr;
     const float* oalpha = nullptr;
     const float* oinv_beta = nullptr;
-    int ogelu = 0;
     int Cin = 0, M = 0, Mp = 0, dil = 1, Lin = 0, stride = 1, Cout = 0, clamp = 0, B = 0;
     int n_tiles = 0, tiles_l = 0, tiles_m = 0;
     int my_fast = 0;   // tile order, see conv_split_kernel
@@ -404,7 +403,6 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(SplitArgs a) {
                                     const float sn = __sinf(a.oalpha[mg + q] * t);
                                     t = t + a.oinv_beta[mg + q] * (sn * sn);
                                 }
-                                if (a.ogelu) t = gelu_erf(t);
                                 const _Float16 hi = (_Float16)fminf(fmaxf(t, -65504.f), 65504.f);
                                 vh[q] = hi;
                                 vl[q] = (_Float16)((t - (float)hi) * 2048.0f);
@@ -998,7 +996,8 @@ static int voc_conv_split(Voc* v, const VocOp& op, const VocOp* next, bool last,
         if (!st.f32_cur) return -1;   // the producer keeps an f32 copy whenever its consumer saves a residual
         st.res = v->buf[st.f32_idx];
     }
-    const bool want_planes = next && split_capable(*next) && op.op == VOP_CONV && op.cout % 16 == 0;
+    // (a GELU consumer takes its planes from the separate pass: erf in this epilogue costs every conv registers)
+    const bool want_planes = next && split_capable(*next) && op.op == VOP_CONV && op.cout % 16 == 0 && !(next->flags & VF_GELU);
     const bool want_f32 = !want_planes || last || (next->flags & VF_RES_SAVE);
     SplitArgs sa;
     sa.xh = v->plane[2 * in_set];
@@ -1035,7 +1034,6 @@ static int voc_conv_split(Voc* v, const VocOp& op, const VocOp* next, bool last,
             sa.oalpha = next->alpha;
             sa.oinv_beta = next->inv_beta;
         }
-        sa.ogelu = (next->flags & VF_GELU) ? 1 : 0;
     }
     if (launch_conv_split(v->s, sa, KT, B)) return -1;
     if (want_f32) {

@@ -141,6 +141,11 @@ def test_full_size_table_is_causal_and_deterministic(gpu_lib, tmp_path_factory):
     assert not np.array_equal(out[0, 48 * 1920:], out[1, 48 * 1920:])
     np.testing.assert_array_equal(v.decode(a[None])[0], out[0])          # alone == inside a batch
     np.testing.assert_array_equal(v.decode(np.stack([a, b, c])), out)    # deterministic
+    # coarse speed guard (a register spill in the conv kernel once cost 2.6x unnoticed by the parity checks):
+    # 3 chunks = 0.92 TFLOP of fp32-equivalent work take ~7 ms on an MI355X; 30 ms means something broke
+    ms = float(gpu_lib.voc_last_decode_ms(v.h))
+    print("full table, 3 chunks:", ms, "ms")
+    assert ms < 30.0
     v.close()
 
 
