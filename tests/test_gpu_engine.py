@@ -118,3 +118,27 @@ def test_engine_ignore_eos_fixed_length(gpu_lib, world):
     _compare(codes, per, [ref], [mm])
     assert eng.last_run_ms > 0 and eng.step_weight_bytes > 1e8
     eng.destroy()
+
+
+def test_full_depth_frame_graph_speed_guard(gpu_lib):
+    """Coarse guard on the frame graph at the real depth (28 + 16 x 5 layer passes, 560 graph nodes): one
+    frame of 4 utterances replays in ~3 ms on an MI355X; 9 ms means a kernel of the chain fell off a cliff
+    (a spill, a lost overlap) that the parity checks cannot see.  Also: replaying is deterministic."""
+    from tests.util import synthetic_pack
+    path, cfg, _ = synthetic_pack(28, 5)
+    rng = np.random.default_rng(5)
+    prefixes = _prefixes(rng, [12, 20, 9, 31])
+    pad = (0.03 * rng.standard_normal(1024)).astype(np.float32)
+    outs = []
+    for _ in range(2):
+        eng = FrameEngine(path, max_batch=4, n_ctx=96, max_frames=24)
+        eng.set_pad_embed(pad)
+        eng.start(prefixes, [3, 11, 0, 22], ignore_eos=True, max_frames=24)
+        assert eng.run(8) == 8            # first call: eager frame + capture
+        assert eng.run(16) == 16          # replays only
+        ms = eng.last_run_ms / 16
+        outs.append(eng.codes()[0].copy())
+        eng.destroy()
+    print("full-depth frame graph:", ms, "ms per frame at 4 utterances")
+    np.testing.assert_array_equal(outs[0], outs[1])
+    assert ms < 9.0
