@@ -349,6 +349,19 @@ def main():
                                        "fp32_equivalent_tflops": round(fl / (voc_ms * 1e-3) / 1e12, 2),
                                        "avg_launch_ms": round(voc_ms, 3),
                                        "avg_launch_ms_beside_frame_loop": round(voc_ms_step, 3)}
+        # the same vocoder with the exact-fp32 MFMA arithmetic (Q3_VOC_EXACT=1), for whoever prices the default
+        # split arithmetic as something other than fp32: one decode alone, and two whole steps (rank 0, N = 1)
+        if world == 1 and os.environ.get("Q3_VOC_EXACT", "0") in ("", "0"):
+            lib.voc_set_exact_fp32(1)
+            voc.decode(codes_alone.copy())
+            ex_ms = float(voc.ms[-1])
+            dt_ex, _, _, _ = run_leg(eng, voc, prefixes, n_text, pad, F, 2, 1, sync_all)
+            lib.voc_set_exact_fp32(0)
+            out["vocoder_exact_fp32"] = {"avg_launch_ms": round(ex_ms, 3), "achieved": round(fl / (ex_ms * 1e-3) / 1e12, 2),
+                                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": round(fl / (ex_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                         "value_with_exact_vocoder": round(aggregate_value(1, B, F, 2, dt_ex), 1),
+                                         "ms_per_step_with_exact_vocoder": round(dt_ex / 2 * 1e3, 3)}
         voc.close()
     eng.destroy()
     if world == 1 and not a.no_b1:
