@@ -208,7 +208,8 @@ typedef _Float16 hv8 __attribute__((ext_vector_type(8)));
 
 __global__ void __launch_bounds__(256) snake_split_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
                                                           const float* __restrict__ inv_beta, _Float16* __restrict__ xh,
-                                                          _Float16* __restrict__ xl, int C, int L, int gelu) {
+                                                          _Float16* __restrict__ xl, int C, int L, int gelu,
+                                                          int* __restrict__ ovf) {
     const int l = blockIdx.x * 256 + threadIdx.x, cg = blockIdx.y, b = blockIdx.z;   // cg: 8-channel group
     if (l >= L) return;
     const float* xp = x + ((size_t)b * C + cg * 8) * L + l;
@@ -227,8 +228,10 @@ __global__ void __launch_bounds__(256) snake_split_kernel(const float* __restric
         for (int j = 0; j < 8; j++) v[j] = gelu_erf(v[j]);
     }
     hv8 h, lo;
+    bool big = false;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
+        big |= !(fabsf(v[j]) <= 65504.f);   // beyond the hi term's range (or NaN): the split form cannot carry it
         const _Float16 hi = (_Float16)fminf(fmaxf(v[j], -65504.f), 65504.f);
         h[j] = hi;
         lo[j] = (_Float16)((v[j] - (float)hi) * 2048.0f);
@@ -236,6 +239,7 @@ __global__ void __launch_bounds__(256) snake_split_kernel(const float* __restric
     const size_t o = (((size_t)b * (C >> 3) + cg) * L + l) * 8;
     *(hv8*)(xh + o) = h;
     *(hv8*)(xl + o) = lo;
+    if (big) *ovf = 1;
 }
 
 struct SplitArgs {
@@ -252,6 +256,7 @@ struct SplitArgs {
     _Float16* ol = nullptr;
     const float* oalpha = nullptr;
     const float* oinv_beta = nullptr;
+    int* ovf = nullptr;                  // set to 1 when an output plane value leaves the fp16 range
     int Cin = 0, M = 0, Mp = 0, dil = 1, Lin = 0, stride = 1, Cout = 0, clamp = 0, B = 0;
     int n_tiles = 0, tiles_l = 0, tiles_m = 0;
     int my_fast = 0;   // tile order, see conv_split_kernel
@@ -396,6 +401,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(SplitArgs a) {
                         }
                         if (a.oh && mg < a.M) {
                             hv4 vh, vl;
+                            bool big = false;
 #pragma unroll
                             for (int q = 0; q < 4; q++) {
                                 float t = v[q];
@@ -403,10 +409,12 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(SplitArgs a) {
                                     const float sn = __sinf(a.oalpha[mg + q] * t);
                                     t = t + a.oinv_beta[mg + q] * (sn * sn);
                                 }
+                                big |= !(fabsf(t) <= 65504.f);
                                 const _Float16 hi = (_Float16)fminf(fmaxf(t, -65504.f), 65504.f);
                                 vh[q] = hi;
                                 vl[q] = (_Float16)((t - (float)hi) * 2048.0f);
                             }
+                            if (big) *a.ovf = 1;
                             const size_t o = (((size_t)b * (a.Cout >> 3) + (mg >> 3)) * a.Lin + l) * 8 + (mg & 7);
                             *(hv4*)(a.oh + o) = vh;
                             *(hv4*)(a.ol + o) = vl;
@@ -614,6 +622,8 @@ struct Voc {
     hipStream_t s = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int64_t* d_codes = nullptr;
+    int* d_ovf = nullptr;          // split path: an activation left the fp16 range (the call is redone exactly)
+    bool warned_ovf = false;
     float *buf[3] = {nullptr, nullptr, nullptr};
     _Float16 *plane[4] = {nullptr, nullptr, nullptr, nullptr};   // two {hi, lo} plane sets (split path): a conv's input and output
     size_t buf_elems = 0;
@@ -657,6 +667,7 @@ static void voc_destroy(Voc* v) {
     for (_Float16* b : v->plane)
         if (b) hipFree(b);
     if (v->d_codes) hipFree(v->d_codes);
+    if (v->d_ovf) hipFree(v->d_ovf);
     if (v->e0) hipEventDestroy(v->e0);
     if (v->e1) hipEventDestroy(v->e1);
     if (v->s) hipStreamDestroy(v->s);
@@ -805,28 +816,32 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
                 const int Mrows = op.op == VOP_CONV ? op.cout : op.cout * op.p0;
                 const int Mp = Mrows % 96 == 0 ? Mrows : (Mrows + 127) / 128 * 128;   // 96- or 64-row tiles, in bounds
                 std::vector<uint16_t> hi((size_t)(op.cin / 16) * KTAPS * Mp * 16, 0), lo(hi.size(), 0);
+                bool in_range = true;   // a weight beyond the fp16 range keeps this op on the exact path
                 for (int k = 0; k < KTAPS; k++)
                     for (int m = 0; m < Mrows; m++)
                         for (int ci = 0; ci < op.cin; ci++) {
                             const float wv = wk[((size_t)k * Mrows + m) * op.cin + ci];
+                            in_range = in_range && fabsf(wv) <= 65504.f;
                             const uint16_t h = f2h_sat(wv);
                             const size_t d = ((((size_t)(ci >> 4) * KTAPS + k) * Mp) + m) * 16 + (ci & 15);
                             hi[d] = h;
                             lo[d] = f2h_sat((wv - h2f(h)) * 2048.0f);
                         }
                 void *dh = nullptr, *dl = nullptr;
-                if (hipMalloc(&dh, hi.size() * 2) != hipSuccess || hipMalloc(&dl, lo.size() * 2) != hipSuccess) {
-                    ok = false;
-                    break;
+                if (in_range) {
+                    if (hipMalloc(&dh, hi.size() * 2) != hipSuccess || hipMalloc(&dl, lo.size() * 2) != hipSuccess) {
+                        ok = false;
+                        break;
+                    }
+                    v->allocs.push_back(dh);
+                    v->allocs.push_back(dl);
+                    ok = hipMemcpy(dh, hi.data(), hi.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
+                         hipMemcpy(dl, lo.data(), lo.size() * 2, hipMemcpyHostToDevice) == hipSuccess;
+                    op.w_hi = (_Float16*)dh;
+                    op.w_lo = (_Float16*)dl;
+                    op.Mp128 = Mp;
+                    if (!ok) break;
                 }
-                v->allocs.push_back(dh);
-                v->allocs.push_back(dl);
-                ok = hipMemcpy(dh, hi.data(), hi.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
-                     hipMemcpy(dl, lo.data(), lo.size() * 2, hipMemcpyHostToDevice) == hipSuccess;
-                op.w_hi = (_Float16*)dh;
-                op.w_lo = (_Float16*)dl;
-                op.Mp128 = Mp;
-                if (!ok) break;
             }
             {   // [tap][row][cin] -> stage-major [cin/8][tap][cin%8][Mp]
                 const int KTAPS = op.op == VOP_CONV ? op.k : op.k / op.p0;
@@ -943,6 +958,7 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
         for (int i = 0; i < 3 && ok; i++) ok = hipMalloc((void**)&v->buf[i], v->buf_elems * 4) == hipSuccess;
         for (int i = 0; i < 4 && ok; i++) ok = hipMalloc((void**)&v->plane[i], v->buf_elems * 2) == hipSuccess;
         ok = ok && hipMalloc((void**)&v->d_codes, sizeof(int64_t) * 16 * v->chunk * v->max_batch) == hipSuccess;
+        ok = ok && hipMalloc((void**)&v->d_ovf, 16) == hipSuccess && hipMemset(v->d_ovf, 0, 16) == hipSuccess;
     }
     if (!ok) {
         Q3_LOG("voc_load failed");
@@ -989,7 +1005,7 @@ static int voc_conv_split(Voc* v, const VocOp& op, const VocOp* next, bool last,
         in_set = 0;
         hipLaunchKernelGGL(snake_split_kernel, dim3((unsigned)((L + 255) / 256), op.cin / 8, B), dim3(256), 0, v->s,
                            v->buf[st.f32_idx], op.alpha, op.inv_beta, v->plane[0], v->plane[1], op.cin, (int)L,
-                           (op.flags & VF_GELU) ? 1 : 0);
+                           (op.flags & VF_GELU) ? 1 : 0, v->d_ovf);
         Q3_HIP(hipGetLastError(), -1);
     }
     if (op.flags & VF_RES_SAVE) {
@@ -1005,6 +1021,7 @@ static int voc_conv_split(Voc* v, const VocOp& op, const VocOp* next, bool last,
     sa.w_hi = op.w_hi;
     sa.w_lo = op.w_lo;
     sa.bias = op.bias;
+    sa.ovf = v->d_ovf;
     sa.res = (op.flags & VF_RES_ADD) ? st.res : nullptr;
     sa.Cin = op.cin;
     sa.Cout = op.cout;
@@ -1047,7 +1064,7 @@ static int voc_conv_split(Voc* v, const VocOp& op, const VocOp* next, bool last,
 }
 
 static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = nullptr, long* outL = nullptr,
-                   float* op_ms = nullptr) {
+                   float* op_ms = nullptr, bool force_exact = false) {
     // ping-pong between buf[0]/buf[1]; buf[2] keeps the residual-unit input (exact path)
     int cur = 0;
     int C = 0;
@@ -1096,7 +1113,7 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
             st.f32_idx = cur;
             st.f32_cur = true;
             st.planes = -1;
-        } else if (g_voc_split && op.w_hi) {
+        } else if (g_voc_split && !force_exact && op.w_hi) {
             const bool last = i + 1 == nrun;
             const VocOp* next = (i + 1 < v->ops.size()) ? &v->ops[i + 1] : nullptr;
             if (voc_conv_split(v, op, last ? nullptr : next, last, B, C, L, st)) {
@@ -1170,8 +1187,22 @@ int voc_decode(void* vv, const int64_t* codes, int B, float* out) {
     float* res = nullptr;
     if (voc_run(v, B, &res)) return -1;
     Q3_HIP(hipEventRecord(v->e1, v->s), -1);
+    int ovf = 0;
+    if (g_voc_split) Q3_HIP(hipMemcpyAsync(&ovf, v->d_ovf, sizeof(int), hipMemcpyDeviceToHost, v->s), -1);
     Q3_HIP(hipMemcpyAsync(out, res, sizeof(float) * (size_t)B * v->chunk * v->upsample, hipMemcpyDeviceToHost, v->s), -1);
     Q3_HIP(hipStreamSynchronize(v->s), -1);
+    if (ovf) {
+        // an activation beyond +-65504 (or a NaN): two fp16 terms cannot carry it -- this call is redone on the
+        // exact-fp32 MFMA path, so the split arithmetic never degrades a result silently
+        if (!v->warned_ovf) Q3_LOG("vocoder: activation outside the fp16 range, decoding this call with the exact-fp32 path");
+        v->warned_ovf = true;
+        Q3_HIP(hipMemsetAsync(v->d_ovf, 0, sizeof(int), v->s), -1);
+        Q3_HIP(hipEventRecord(v->e0, v->s), -1);
+        if (voc_run(v, B, &res, -1, nullptr, nullptr, nullptr, true)) return -1;
+        Q3_HIP(hipEventRecord(v->e1, v->s), -1);
+        Q3_HIP(hipMemcpyAsync(out, res, sizeof(float) * (size_t)B * v->chunk * v->upsample, hipMemcpyDeviceToHost, v->s), -1);
+        Q3_HIP(hipStreamSynchronize(v->s), -1);
+    }
     hipEventElapsedTime(&v->last_ms, v->e0, v->e1);
     return 0;
 }

@@ -196,3 +196,34 @@ def test_transformer_and_convnext_ops_match_torch_reference(gpu_lib, tiny_full_v
     assert np.abs(ref).max() > 0.05 and np.abs(got - ref).max() < 2e-4
     v.close()
     lib.voc_set_exact_fp32(0)
+
+
+def test_split_arithmetic_falls_back_when_out_of_fp16_range(gpu_lib, tiny_voc, tmp_path):
+    """Two fp16 terms cannot carry |x| > 65504: a call whose activations leave that range is redone on the
+    exact-fp32 path (bit-identical to the exact mode), and an op with such a weight never leaves it."""
+    path, vc, tensors = tiny_voc
+    big = {k: np.array(v) for k, v in tensors.items()}
+    big["voc.op0.codebook"] = (big["voc.op0.codebook"] * 3.0e5).astype(np.float32)     # RVQ output ~1e6
+    big["voc.op1.weight"] = (big["voc.op1.weight"] * 1.0e-6).astype(np.float32)        # ... scaled back by the first conv
+    p_act = str(tmp_path / "voc_big_act.q3w")
+    W.write_pack(p_act, {"voc_chunk": 64.0}, big)
+    bigw = {k: np.array(v) for k, v in tensors.items()}
+    w2 = bigw["voc.op2.weight"].copy()
+    w2.flat[0] = 1.0e5                                                                  # one weight beyond fp16
+    bigw["voc.op2.weight"] = w2
+    p_w = str(tmp_path / "voc_big_w.q3w")
+    W.write_pack(p_w, {"voc_chunk": 64.0}, bigw)
+    codes = np.random.default_rng(17).integers(0, 2048, size=(2, 64, 16)).astype(np.int64)
+    for p in (p_act, p_w):
+        outs = {}
+        for exact in (1, 0):
+            gpu_lib.voc_set_exact_fp32(exact)
+            v = Voc(gpu_lib, p, max_batch=2)
+            outs[exact] = v.decode(codes).copy()
+            v.close()
+        gpu_lib.voc_set_exact_fp32(0)
+        assert np.isfinite(outs[0]).all()
+        if p == p_act:
+            np.testing.assert_array_equal(outs[0], outs[1])        # the whole call was redone exactly
+        else:
+            assert np.abs(outs[0] - outs[1]).max() < 2e-4          # that op exact, the others split
