@@ -82,3 +82,52 @@ def test_three_servers_and_client(gpu_lib, packs, tmp_path):
         s._running = False
     for t in threads:
         t.join(timeout=5)
+
+
+def test_batch_server_matches_single_utterance_path(gpu_lib, packs, tmp_path):
+    """The batched request (one socket message, B utterances through the on-device frame loop + vocoder) returns,
+    for every utterance, the codec ids of the fused engine run on the same batch and the PCM of the vocoder's chunk
+    walk over those ids -- ragged lengths and an empty text included (utterances of one batch share the ragged
+    prefill, whose tile shapes depend on the total row count, so ids are compared batch against the same batch); a
+    malformed request gets the error sentinel and the server keeps serving."""
+    import socket
+    import struct
+    from qwen3_tts_axera_russian_amd import batch_server as bs
+    from qwen3_tts_axera_russian_amd.engine import FrameEngine
+    from qwen3_tts_axera_russian_amd.vocoder_server import VocoderServer
+    main, voc, cfg = packs
+    sock = str(tmp_path / "batch.sock")
+    srv = bs.BatchSynthesisServer(main, voc, sock, max_batch=4, n_ctx=128, max_tokens=70, temperature=0.0,
+                                  cp_temperature=0.0, install_signal_handlers=False)
+    th = threading.Thread(target=srv.serve, daemon=True)
+    th.start()
+    _wait(sock)
+    reqs = [[5, 17, 200, 33, 41, 7, 90, 120, 64, 3, 11, 250, 77, 8, 19, 300, 45, 60, 2, 150, 99, 21, 13, 55, 180],
+            [9, 8, 7], [], [301, 302, 303, 304, 305, 306, 307, 308, 309, 310, 311, 312]]
+    res = bs.synthesize_batch(sock, token_ids=reqs)
+    assert len(res) == 4
+    eng = FrameEngine(main, max_batch=4, n_ctx=128, max_frames=70)
+    eng.set_pad_embed(srv.front.tts_pad_embed)
+    eng.start([srv.front.build_prefix(ids) for ids in reqs], [len(ids) for ids in reqs], ignore_eos=False, max_frames=70)
+    eng.run(70)
+    ecodes, per = eng.codes()
+    eng.destroy()
+    vs = VocoderServer(voc, str(tmp_path / "unused.sock"), install_signal_handlers=False)
+    for b, (codes, pcm) in enumerate(res):
+        n = int(per[b])
+        assert codes.shape == (n, 16) and n >= 1
+        np.testing.assert_array_equal(codes, ecodes[:n, b, :])
+        assert (codes >= 0).all() and (codes < 2048).all()
+        np.testing.assert_array_equal(pcm, vs.synthesize_int16(codes.astype(np.int64)))
+        assert len(pcm) >= n * 1920
+    assert len({int(x) for x in per}) > 1          # the utterances really ended at different frames
+    # too many utterances -> error sentinel; the next request is served
+    s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    s.connect(sock)
+    s.sendall(bs.pack_batch_request(token_ids=[[1]] * 5))
+    assert struct.unpack("<i", s.recv(4))[0] == -2
+    s.close()
+    assert len(bs.synthesize_batch(sock, token_ids=[[9, 8, 7]])) == 1
+    srv._running = False
+    th.join(timeout=5)
+    srv.close()
