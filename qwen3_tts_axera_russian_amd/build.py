@@ -40,17 +40,24 @@ def build(force: bool = False, verbose: bool = False, timeline: bool = False) ->
     hdrs += [os.path.join(HERE, "..", "include", f) for f in os.listdir(os.path.join(HERE, "..", "include"))]
     tag = "_tl" if timeline else ""
     out = os.path.join(LIB, f"libqwen3tts{tag}.so")
-    objs = []
+    objs, jobs = [], []
     for s in srcs:
         o = os.path.join(LIB, os.path.basename(s) + tag + ".o")
         objs.append(o)
         if not force and _newer(o, [s] + hdrs):
             continue
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", s, "-o", o,
-               "-Wno-unused-result", "-Wno-unused-value", "-Wno-pass-failed"] + (["-DQ3_TIMELINE"] if timeline else []) + EXTRA
+        jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", s, "-o", o,
+                     "-Wno-unused-result", "-Wno-unused-value", "-Wno-pass-failed"] + (["-DQ3_TIMELINE"] if timeline else []) + EXTRA)
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+
+    if jobs:   # independent translation units: a few at a time (each hipcc is one core and < 2 GiB)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as pool:
+            list(pool.map(run, jobs))
     if force or not _newer(out, objs):
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs + ["-lz"]
         if verbose:
