@@ -615,6 +615,7 @@ __global__ void __launch_bounds__(1024) attn_kernel(AttnArgs a) {
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    Q3_PH(0);  // loads issued
 
     // ---- phase A: per-head RMSNorm + RoPE (rotate-half pairs i, i+64) ----
     if (MODE != ATTN_ATTEND) {
@@ -653,6 +654,7 @@ __global__ void __launch_bounds__(1024) attn_kernel(AttnArgs a) {
         if (tid < 2 * D) qs[tid / D][tid % D] = qpre;
     }
     __syncthreads();
+    Q3_PH(1);  // phase A done (first global round trip + norm + rope), barrier passed
 
     // ---- phase B: online softmax per 16-lane group ----
     float q0[8], q1[8];
@@ -713,6 +715,8 @@ __global__ void __launch_bounds__(1024) attn_kernel(AttnArgs a) {
         }
         step(kk, vv);
     }
+    asm volatile("" ::"v"(a0[0]), "v"(l0));
+    Q3_PH(2);  // cached rows + the new token processed
     // merge the 4 groups of a wave (lanes xor 16, 32), then the waves through LDS
 #pragma unroll
     for (int o = 16; o <= 32; o <<= 1) {
@@ -747,6 +751,7 @@ __global__ void __launch_bounds__(1024) attn_kernel(AttnArgs a) {
         }
     }
     __syncthreads();
+    Q3_PH(3);  // groups merged, partials in LDS, barrier passed
     if (tid < 2 * D) {
         const int hh = tid / D, d = tid % D;
         float M = -INFINITY;
@@ -762,11 +767,144 @@ __global__ void __launch_bounds__(1024) attn_kernel(AttnArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// attention over a short cache (code predictor: at most 15 cached positions + the token being appended):
+// same phase A; then every 16-lane group scores at most two entries and parks them in LDS, and every
+// (head, dim) thread finishes its own output -- max, exponentials, weighted sum over <= 32 entries with the
+// V column it prefetched at kernel start.  No merge of partial softmaxes across groups and waves: two
+// barriers, one short serial tail (the general kernel's merge + combine cost 1.9 of its 3.7 us here).
+// ---------------------------------------------------------------------------
+constexpr int ATTN_SHORT_MAX_T = 15;
+static int g_attn_short = 1;
+int set_attn_short(int on) { g_attn_short = on; return 0; }
+__global__ void __launch_bounds__(256) attn_short_kernel(AttnArgs a) {
+    constexpr int D = 128, NE = ATTN_SHORT_MAX_T + 1;   // entries: <= 15 cached rows + the appended token
+    Q3_TL(33);
+    const int r = a.row0 + blockIdx.x, g = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int slot = a.slot ? a.slot[r] : a.slot_base + r * a.slot_stride;
+    const int T = a.pos_base;                       // cached rows = position of the appended token (row-uniform)
+    __shared__ float qs[2][D];
+    __shared__ float knew[D];
+    __shared__ __attribute__((aligned(16))) half_t vs[NE][D];   // V rows of the entries (row T = the appended token)
+    __shared__ __attribute__((aligned(16))) float sc[2][NE];
+    float* row = a.qkv + (size_t)r * a.ld;
+    const size_t cbase = ((size_t)slot * a.n_kv + g) * (size_t)a.n_ctx * D;
+    const int l16 = tid & 15, grp = tid >> 4;       // 16 groups of 16 lanes: group e owns entry e
+    const int hh = tid >> 7, d = tid & 127;         // the output this thread finishes
+    // ---- every global load, issued up front: phase A operands, then this group's cached K and V row ----
+    float x0 = 0.f, x1 = 0.f, gm0 = 1.f, gm1 = 1.f, cs = 1.f, sn = 0.f;
+    {
+        const float* src = w < 2 ? row + (size_t)(2 * g + w) * D
+                         : w == 2 ? row + (size_t)(a.n_heads + g) * D
+                                  : row + (size_t)(a.n_heads + a.n_kv + g) * D;
+        x0 = src[lane];
+        x1 = src[lane + 64];
+        if (w < 3) {
+            const float* gam = w < 2 ? a.q_norm : a.k_norm;
+            gm0 = gam[lane];
+            gm1 = gam[lane + 64];
+            cs = a.rope_cos[(size_t)T * 64 + lane];
+            sn = a.rope_sin[(size_t)T * 64 + lane];
+        }
+    }
+    h8 kpre, vpre;
+    if (grp < T) {
+        kpre = *(const h8*)(a.kc + cbase + (size_t)grp * D + l16 * 8);
+        vpre = *(const h8*)(a.vc + cbase + (size_t)grp * D + l16 * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    Q3_PH(0);
+    // ---- phase A: per-head RMSNorm + RoPE, K/V appended (identical arithmetic to attn_kernel) ----
+    if (w < 3) {
+        float ss = wave_sum(x0 * x0 + x1 * x1);
+        const float iv = 1.0f / sqrtf(ss / (float)D + a.eps);
+        x0 = (x0 * iv) * gm0;
+        x1 = (x1 * iv) * gm1;
+        const float y0 = x0 * cs - x1 * sn;
+        const float y1 = x1 * cs + x0 * sn;
+        x0 = y0;
+        x1 = y1;
+    }
+    if (w < 2) {
+        qs[w][lane] = x0;
+        qs[w][lane + 64] = x1;
+    } else {
+        const half_t h0 = sat_half(x0), h1 = sat_half(x1);
+        half_t* cd = (w == 2 ? a.kc : a.vc) + cbase + (size_t)T * D;
+        cd[lane] = h0;
+        cd[lane + 64] = h1;
+        if (w == 2) {
+            knew[lane] = (float)h0;
+            knew[lane + 64] = (float)h1;
+        } else {
+            vs[T][lane] = h0;
+            vs[T][lane + 64] = h1;
+        }
+    }
+    if (grp < T) *(h8*)(&vs[grp][l16 * 8]) = vpre;   // cached V rows parked for the last phase
+    __syncthreads();
+    Q3_PH(1);
+    // ---- scores: entry e < T from the cache, entry T = the appended token (fp16-rounded, from LDS) ----
+    if (grp <= T) {   // uniform per 16-lane group
+        float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float kf = grp < T ? (float)kpre[j] : knew[l16 * 8 + j];
+            d0 += (qs[0][l16 * 8 + j] * a.scale) * kf;
+            d1 += (qs[1][l16 * 8 + j] * a.scale) * kf;
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            d0 += __shfl_xor(d0, o, 16);
+            d1 += __shfl_xor(d1, o, 16);
+        }
+        if (l16 == 0) {
+            sc[0][grp] = d0;
+            sc[1][grp] = d1;
+        }
+    }
+    __syncthreads();
+    Q3_PH(2);
+    // ---- every (head, dim) thread: softmax over the T+1 scores, weighted sum of its V column ----
+    float sv[NE];
+#pragma unroll
+    for (int e4 = 0; e4 < NE; e4 += 4) {     // 4 broadcast reads of 16 B
+        const float4 t4 = *(const float4*)(&sc[hh][e4]);
+        sv[e4] = t4.x;
+        sv[e4 + 1] = t4.y;
+        sv[e4 + 2] = t4.z;
+        sv[e4 + 3] = t4.w;
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < NE; e++) m = fmaxf(m, e <= T ? sv[e] : -INFINITY);
+    float L = 0.f, o = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; e++) {
+        const float p = e <= T ? __expf(sv[e] - m) : 0.f;       // (rows beyond T hold stale LDS: masked, never NaN-multiplied)
+        const float vf = e <= T ? (float)vs[e][d] : 0.f;
+        L += p;
+        o += p * vf;
+    }
+    Q3_PH(3);
+    a.out[frag_idx(r, (2 * g + hh) * D + d, a.n_heads * D)] = sat_half(o / L);
+}
+
 int launch_attn(hipStream_t s, const AttnArgs& a, int mode) {
     if (a.R <= 0) return 0;
     if (a.n_heads != 2 * a.n_kv) {
         Q3_LOG("attn: only GQA group 2 (16q/8kv) is built, got %d/%d", a.n_heads, a.n_kv);
         return -1;
+    }
+    // every row at the same short position, known on the host (the code predictor's passes): the short-cache kernel
+    if (g_attn_short && mode == ATTN_FUSED && !a.pos && a.pos_stride == 0 && a.pos_base >= 0 &&
+        a.pos_base <= ATTN_SHORT_MAX_T && a.pos_base < a.n_ctx) {
+        AttnArgs a3 = a;
+        a3.tl_node = tl_next_node();
+        hipLaunchKernelGGL(attn_short_kernel, dim3(a.R, a.n_kv), dim3(256), 0, s, a3);
+        Q3_HIP(hipGetLastError(), -1);
+        return 0;
     }
     // keep the launch small: ~64K threads fill in ~2 us, every further 64K cost ~1 us of ramp
     int threads = a.threads;

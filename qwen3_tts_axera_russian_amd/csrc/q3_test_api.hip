@@ -8,6 +8,7 @@ namespace q3 {
 int set_linear_tuning(int K, int mt16, int kbw);
 int set_linear_split_rows(int on);
 int set_linear_wide_tiles(int on);
+int set_attn_short(int on);
 }
 
 namespace {
@@ -32,6 +33,7 @@ int q3t_device_count(void) {
 int q3t_set_linear_tuning(int K, int mt16, int kbw) { return set_linear_tuning(K, mt16, kbw); }
 int q3t_set_linear_split_rows(int on) { return set_linear_split_rows(on); }
 int q3t_set_linear_wide_tiles(int on) { return set_linear_wide_tiles(on); }
+int q3t_set_attn_short(int on) { return set_attn_short(on); }
 
 // One linear launch.  W is row-major fp16 [N][K]; gateup != 0 means rows [0,N/2) are gate and
 // [N/2,N) up (tile-interleaved on the device like the model loader does).
