@@ -1176,6 +1176,8 @@ __global__ void __launch_bounds__(256) cp_argmax_kernel(CpArgmaxArgs a) {
     float4 l0 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), l1 = l0;
     if (tid < n4) l0 = lg[tid];
     if (tid + 256 < n4) l1 = lg[tid + 256];
+    const int nf_r = a.n_frames[r];   // independent of the arg-max: requested with the logits, not after them
+    Q3_PH(0);
     {
         const float e[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
 #pragma unroll
@@ -1211,6 +1213,7 @@ __global__ void __launch_bounds__(256) cp_argmax_kernel(CpArgmaxArgs a) {
         si[tid >> 6] = bidx;
     }
     __syncthreads();
+    Q3_PH(1);  // logits landed, wave arg-max done, barrier passed
     best = sv[0];
     bidx = si[0];
 #pragma unroll
@@ -1228,14 +1231,15 @@ __global__ void __launch_bounds__(256) cp_argmax_kernel(CpArgmaxArgs a) {
         __syncthreads();
         for (int v = tid; v < a.V; v += 256) slg[v] = a.logits[(size_t)r * a.V + v];
         __syncthreads();
-        const float u = uniform01(a.seed, (unsigned)r, (unsigned)a.n_frames[r], 1u + (unsigned)a.group);
+        const float u = uniform01(a.seed, (unsigned)r, (unsigned)nf_r, 1u + (unsigned)a.group);
         bidx = block_sample_topk(slg, a.V, a.top_k, a.temperature, 0.f, u, sv2, si2, selv, seli);
     }
-    int f = a.n_frames[r] - 1;
+    int f = nf_r - 1;
     if (f < 0) f = 0;
     if (f >= a.frame_cap) f = a.frame_cap - 1;
     int* fc = a.codes + ((size_t)f * RT + r) * 16;
     if (tid == 0) fc[1 + a.group] = bidx;
+    Q3_PH(2);
     if (a.talker_emb) {
         feedback_row(fc, r, a.talker_emb, a.talker_vocab, a.cp_tables, a.V, a.n_groups, a.pad_embed,
                      a.h_out, a.ssq_out, a.H, a.group, bidx);
