@@ -15,6 +15,10 @@
 //                   embedding gather, and tts_client.py:199-208 feedback sum.
 #include "q3_kernels.h"
 
+#ifndef Q3_NORM_FIRST
+#define Q3_NORM_FIRST 1
+#endif
+
 namespace q3 {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -160,6 +164,7 @@ __global__ void __launch_bounds__(NW * 64)
     a.eps = p_eps;
     constexpr int MR = MT16 * 16, NB = NB16 * 16, NBP = NB + 4, KB = NW * KBW, K = KB * 32;
     constexpr int NTH = NW * 64;
+    constexpr bool NORM_FIRST = Q3_NORM_FIRST != 0;
     constexpr int NOUT = (EPI == EPI_SWIGLU) ? MR * NB / 2 : MR * NB;   // outputs of this workgroup
     constexpr int OPT = (NOUT + NTH - 1) / NTH;                         // outputs per thread
     constexpr int SQI = (MR * 16 + NTH - 1) / NTH;                      // ssq float4 groups per thread
@@ -201,16 +206,21 @@ __global__ void __launch_bounds__(NW * 64)
             if (o < NOUT && m < a.M) hold[i] = a.h_out[frag_idx(m, tile0 * 16 + (o % NB), a.N)];
         }
     }
-    // (b) the weight stream (HBM, the long pole): everything this wave will need, in flight at once
+    // (b) / (c): the weight stream (HBM, the long pole: everything this wave will need, in flight at once) and the
+    // activation fragments (L2).  PRO_F16 fragments feed the MFMA as they are: weights first, fragments last.
+    // PRO_NORM fragments still have to be scaled and rounded, so (g_norm_first) they are requested ahead of the
+    // weights: vmcnt retires in order, they land first and the conversion runs under the weight stream's latency.
     h8 wf[NB16][KBW];
+    auto load_weights = [&]() {
 #pragma unroll
-    for (int nb = 0; nb < NB16; nb++)
+        for (int nb = 0; nb < NB16; nb++)
 #pragma unroll
-        for (int kbi = 0; kbi < KBW; kbi++) {
-            const h8* p = (const h8*)(a.wp + (((size_t)(tile0 + nb) * KB + (size_t)w * KBW + kbi) * 64 + lane) * 8);
-            wf[nb][kbi] = NT ? __builtin_nontemporal_load(p) : *p;
-        }
-    // (c) the activation fragments (L2)
+            for (int kbi = 0; kbi < KBW; kbi++) {
+                const h8* p = (const h8*)(a.wp + (((size_t)(tile0 + nb) * KB + (size_t)w * KBW + kbi) * 64 + lane) * 8);
+                wf[nb][kbi] = NT ? __builtin_nontemporal_load(p) : *p;
+            }
+    };
+    if (!(PRO == PRO_NORM && NORM_FIRST)) load_weights();
     if (PRO == PRO_NORM) {
 #pragma unroll
         for (int kbi = 0; kbi < KBW; kbi++) {
@@ -235,6 +245,7 @@ __global__ void __launch_bounds__(NW * 64)
             }
         }
     }
+    if (PRO == PRO_NORM && NORM_FIRST) load_weights();
     __builtin_amdgcn_sched_barrier(0);
     Q3_PH(0);  // all loads issued
 
