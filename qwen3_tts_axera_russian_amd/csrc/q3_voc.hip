@@ -262,14 +262,16 @@ struct SplitArgs {
     int my_fast = 0;   // tile order, see conv_split_kernel
 };
 
-constexpr int STN = 256, SKC = 16;  // workgroup tile columns and input channels per k-step
+constexpr int SKC = 16;  // input channels per k-step
 
 // KT taps; KS 16-channel k-steps per LDS stage (few-tap convs stage several, so a barrier pair buys more MFMAs);
 // MW 32-row MFMA tiles per workgroup (rows = 32*MW: 96 divides every channel count of the decoder, so the
 // input tile is read by Cout/96 workgroups instead of Cout/64 and no row is padding)
-template <int KT, int KS, int MW>
-__global__ void __launch_bounds__(256, 2) conv_split_kernel(SplitArgs a) {
-    constexpr int STM = 32 * MW;
+// NJ 32-column tiles per wave (workgroup = 4 waves side by side = 128*NJ columns): 2 for the MFMA-bound layers,
+// 1 for the few-tap HBM-bound ones, whose half-size accumulators let a third workgroup per CU overlap the phases
+template <int KT, int KS, int MW, int NJ>
+__global__ void __launch_bounds__(256, NJ == 1 ? 3 : 2) conv_split_kernel(SplitArgs a) {
+    constexpr int STM = 32 * MW, STN = 128 * NJ;
     constexpr int UNR = (MW == 3 && KT == 7) ? 1 : KS * KT;   // unroll of the tap loop
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int halo = (KT - 1) * a.dil;
@@ -301,11 +303,11 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(SplitArgs a) {
             my = tile / (a.tiles_l * a.B);
         }
         const int l0 = lx * STN, m0 = my * STM;
-        f16v acc[MW][2], accx[MW][2];
+        f16v acc[MW][NJ], accx[MW][NJ];
 #pragma unroll
         for (int i = 0; i < MW; i++)
 #pragma unroll
-            for (int j = 0; j < 2; j++)
+            for (int j = 0; j < NJ; j++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     acc[i][j][r] = 0.f;
@@ -339,7 +341,7 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(SplitArgs a) {
             for (int sk = 0; sk < KS * KT; sk++) {
                 const int ks = sk / KT, k = sk % KT;
                 const int off = k * a.dil;   // tap k reads column l - (KT-1-k)*dil = staged column (l-l0) + k*dil
-                hv8 ah[MW], al[MW], bh[2], bl[2];
+                hv8 ah[MW], al[MW], bh[NJ], bl[NJ];
 #pragma unroll
                 for (int i = 0; i < MW; i++) {
                     const int row = i * 32 + (lane & 31);
@@ -347,15 +349,15 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(SplitArgs a) {
                     al[i] = *(const hv8*)(Wl + (sk * STM + row) * SKC + (lane >> 5) * 8);
                 }
 #pragma unroll
-                for (int i = 0; i < 2; i++) {
-                    const int col = w * 64 + i * 32 + (lane & 31) + off;
+                for (int i = 0; i < NJ; i++) {
+                    const int col = w * (32 * NJ) + i * 32 + (lane & 31) + off;
                     bh[i] = *(const hv8*)(Xh + ((size_t)(ks * 2 + (lane >> 5)) * XW + col) * 8);
                     bl[i] = *(const hv8*)(Xl + ((size_t)(ks * 2 + (lane >> 5)) * XW + col) * 8);
                 }
 #pragma unroll
                 for (int i = 0; i < MW; i++)
 #pragma unroll
-                    for (int j = 0; j < 2; j++) {
+                    for (int j = 0; j < NJ; j++) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                         accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
                         accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
@@ -367,8 +369,8 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(SplitArgs a) {
 #pragma unroll
         for (int i = 0; i < MW; i++)
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int l = l0 + w * 64 + j * 32 + (lane & 31);
+            for (int j = 0; j < NJ; j++) {
+                const int l = l0 + w * (32 * NJ) + j * 32 + (lane & 31);
                 if (l < a.Lin) {
                     float rv[16];
 #pragma unroll
@@ -425,15 +427,15 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(SplitArgs a) {
     }
 }
 
-template <int KT, int KS, int MW>
+template <int KT, int KS, int MW, int NJ>
 static int launch_conv_split_t(hipStream_t s, const SplitArgs& a, int B) {
-    constexpr int STM = 32 * MW;
+    constexpr int STM = 32 * MW, STN = 128 * NJ;
     if (a.dil > 9) return -1;
     const int halo = (KT - 1) * a.dil;
     const size_t lds = ((size_t)2 * KS * KT * STM * SKC + (size_t)2 * KS * (STN + halo) * SKC) * sizeof(_Float16);
     static bool set_ = false;
     if (!set_) {
-        Q3_HIP(hipFuncSetAttribute((const void*)conv_split_kernel<KT, KS, MW>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), -1);
+        Q3_HIP(hipFuncSetAttribute((const void*)conv_split_kernel<KT, KS, MW, NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), -1);
         set_ = true;
     }
     if (lds > 80 * 1024 || (a.Cin / 16) % KS || a.Mp % STM) return -1;   // <= 80 KB: two workgroups per CU
@@ -447,19 +449,27 @@ static int launch_conv_split_t(hipStream_t s, const SplitArgs& a, int B) {
     if (c.my_fast) c.n_tiles = (c.tiles_l * B + 7) / 8 * 8 * c.tiles_m;
     int grid = c.n_tiles;
     if (g_voc_max_wgs > 0 && grid > g_voc_max_wgs) grid = g_voc_max_wgs;
-    hipLaunchKernelGGL((conv_split_kernel<KT, KS, MW>), dim3(grid), dim3(256), lds, s, c);
+    hipLaunchKernelGGL((conv_split_kernel<KT, KS, MW, NJ>), dim3(grid), dim3(256), lds, s, c);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
 }
+
+static int g_voc_narrow_k1 = 1;   // 128-column tiles (three workgroups per CU) for the 1-tap convs
 
 template <int MW>
 static int launch_conv_split_m(hipStream_t s, const SplitArgs& a, int K, int B) {
     const int c16 = a.Cin / 16;
     switch (K) {
-        case 1: return c16 % 3 == 0 ? launch_conv_split_t<1, 3, MW>(s, a, B) : c16 % 2 == 0 ? launch_conv_split_t<1, 2, MW>(s, a, B) : launch_conv_split_t<1, 1, MW>(s, a, B);
-        case 2: return c16 % 2 == 0 ? launch_conv_split_t<2, 2, MW>(s, a, B) : launch_conv_split_t<2, 1, MW>(s, a, B);
-        case 3: return c16 % 2 == 0 && MW == 2 ? launch_conv_split_t<3, 2, MW>(s, a, B) : launch_conv_split_t<3, 1, MW>(s, a, B);
-        case 7: return launch_conv_split_t<7, 1, MW>(s, a, B);
+        case 1:
+            if (g_voc_narrow_k1 && MW == 3)
+                return c16 % 3 == 0 ? launch_conv_split_t<1, 3, MW, 1>(s, a, B) : c16 % 2 == 0 ? launch_conv_split_t<1, 2, MW, 1>(s, a, B) : launch_conv_split_t<1, 1, MW, 1>(s, a, B);
+            return c16 % 3 == 0 ? launch_conv_split_t<1, 3, MW, 2>(s, a, B) : c16 % 2 == 0 ? launch_conv_split_t<1, 2, MW, 2>(s, a, B) : launch_conv_split_t<1, 1, MW, 2>(s, a, B);
+        case 2:
+            if (g_voc_narrow_k1 && MW == 3 && a.Cin <= 384)   // the HBM-bound transposed convs (measured: 1536 -> 768 loses)
+                return c16 % 2 == 0 ? launch_conv_split_t<2, 2, MW, 1>(s, a, B) : launch_conv_split_t<2, 1, MW, 1>(s, a, B);
+            return c16 % 2 == 0 ? launch_conv_split_t<2, 2, MW, 2>(s, a, B) : launch_conv_split_t<2, 1, MW, 2>(s, a, B);
+        case 3: return c16 % 2 == 0 && MW == 2 ? launch_conv_split_t<3, 2, MW, 2>(s, a, B) : launch_conv_split_t<3, 1, MW, 2>(s, a, B);
+        case 7: return launch_conv_split_t<7, 1, MW, 2>(s, a, B);
         default: return -1;
     }
 }
@@ -467,7 +477,7 @@ static int launch_conv_split_m(hipStream_t s, const SplitArgs& a, int K, int B) 
 static int launch_conv_split(hipStream_t s, const SplitArgs& a, int K, int B) {
     // 96-row tiles where they tile the rows exactly (every channel count of the decoder blocks) and still
     // give the chip enough workgroups: the input tile is read by Cout/96 workgroups instead of Cout/64
-    const long tiles96 = (long)((a.Lin + STN - 1) / STN) * (a.M / 96) * B;
+    const long tiles96 = (long)((a.Lin + 255) / 256) * (a.M / 96) * B;
     const bool fits96 = a.M % 96 == 0 && a.Mp % 96 == 0;
     const bool use96 = fits96 && (a.Mp % 64 != 0 || tiles96 >= 512);
     return use96 ? launch_conv_split_m<3>(s, a, K, B) : launch_conv_split_m<2>(s, a, K, B);
@@ -972,6 +982,11 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
 // Cap the number of workgroups every vocoder launch may occupy (0 = no cap).  Process-wide.
 int voc_set_exact_fp32(int on) {
     g_voc_split = on ? 0 : 1;
+    return 0;
+}
+
+int voc_set_narrow_k1(int on) {   // test hook: 128-column tiles for the 1-tap convs (default on)
+    g_voc_narrow_k1 = on ? 1 : 0;
     return 0;
 }
 
