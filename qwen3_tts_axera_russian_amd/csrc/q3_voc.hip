@@ -469,7 +469,9 @@ static int launch_conv_split_m(hipStream_t s, const SplitArgs& a, int K, int B) 
                 return c16 % 2 == 0 ? launch_conv_split_t<2, 2, MW, 1>(s, a, B) : launch_conv_split_t<2, 1, MW, 1>(s, a, B);
             return c16 % 2 == 0 ? launch_conv_split_t<2, 2, MW, 2>(s, a, B) : launch_conv_split_t<2, 1, MW, 2>(s, a, B);
         case 3: return c16 % 2 == 0 && MW == 2 ? launch_conv_split_t<3, 2, MW, 2>(s, a, B) : launch_conv_split_t<3, 1, MW, 2>(s, a, B);
-        case 7: return launch_conv_split_t<7, 1, MW, 2>(s, a, B);
+        case 7:
+            if (g_voc_narrow_k1 && a.Cin <= 192) return launch_conv_split_t<7, 1, MW, 1>(s, a, B);   // the HBM-bound blocks: -4..9 %
+            return launch_conv_split_t<7, 1, MW, 2>(s, a, B);
         default: return -1;
     }
 }
