@@ -397,7 +397,7 @@ int set_linear_wide_tiles(int on) { g_wide_tiles = on; return 0; }
 static int g_split_rows_narrow = 1;
 int set_linear_split_rows(int on) { g_split_rows_narrow = on; return 0; }
 // k-blocks per wave by [K = 1024, 2048, 3072][rows <= 16, <= 32, more]
-static int g_tune_kbw[3][3] = {{8, 4, 4}, {8, 8, 8}, {6, 6, 6}};
+static int g_tune_kbw[3][3] = {{4, 4, 4}, {8, 8, 8}, {6, 6, 6}};
 int set_linear_tuning(int K, int mt16, int kbw) {
     int i = K == 1024 ? 0 : K == 2048 ? 1 : K == 3072 ? 2 : -1;
     int j = mt16 == 1 ? 0 : mt16 == 2 ? 1 : mt16 == 4 ? 2 : -1;
