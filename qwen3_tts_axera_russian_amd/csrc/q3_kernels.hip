@@ -397,7 +397,7 @@ int set_linear_wide_tiles(int on) { g_wide_tiles = on; return 0; }
 static int g_split_rows_narrow = 1;
 int set_linear_split_rows(int on) { g_split_rows_narrow = on; return 0; }
 // k-blocks per wave by [K = 1024, 2048, 3072][rows <= 16, <= 32, more]
-static int g_tune_kbw[3][3] = {{4, 4, 4}, {8, 8, 8}, {6, 6, 6}};
+static int g_tune_kbw[3][3] = {{4, 4, 4}, {16, 8, 8}, {12, 6, 6}};
 int set_linear_tuning(int K, int mt16, int kbw) {
     int i = K == 1024 ? 0 : K == 2048 ? 1 : K == 3072 ? 2 : -1;
     int j = mt16 == 1 ? 0 : mt16 == 2 ? 1 : mt16 == 4 ? 2 : -1;
@@ -445,8 +445,10 @@ int launch_linear(hipStream_t s, const LinArgs& a, int pro, int epi) {
     // K = 2048
     Q3_LIN_MT(1, 8, 8, PRO_F16, EPI_RESID)
     Q3_LIN_MT(1, 4, 16, PRO_F16, EPI_RESID)
+    Q3_LIN_MT(1, 16, 4, PRO_F16, EPI_RESID)
     // K = 3072
     Q3_LIN_MT(1, 6, 16, PRO_F16, EPI_RESID)
+    Q3_LIN_MT(1, 12, 8, PRO_F16, EPI_RESID)
     Q3_LOG("launch_linear: no instantiation for K=%d kbw=%d nw=%d mt16=%d nb16=%d pro=%d epi=%d", K, kbw, nw,
            mt16, nb16, pro, epi);
     return -1;
