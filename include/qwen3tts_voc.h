@@ -49,7 +49,9 @@ int voc_synthesize_max_samples(void* v, int n_tokens);
  * product costs three fp16 MFMAs with f32 accumulation.  1: the exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
  * everywhere.  Measured on MI355X against a float64 evaluation of the same table: max error 2.2e-7 (split)
  * vs 4.0e-7 (exact f32 MFMA) vs 2.1e-7 (torch CPU f32) of full scale -- the split path is fp32-grade, and
- * 2.3x (32 chunks) to 3x (1 chunk) faster.  Process-wide; env Q3_VOC_EXACT=1 selects the exact path at load. */
+ * 2.8x faster at 32 chunks.  Values beyond the fp16 range cannot be split: an op with such a weight stays
+ * exact, and a call in which an activation leaves the range is redone on the exact path before voc_decode
+ * returns.  Process-wide; env Q3_VOC_EXACT=1 selects the exact path at load. */
 int voc_set_exact_fp32(int on);
 
 /* Cap the workgroups each vocoder kernel launch occupies (0 = one per output tile).  With a cap the
