@@ -6,6 +6,8 @@ Outputs (git-ignored, shipped to the GPU box by gpurun):
     lib/libqwen3tts.so     every C-ABI symbol of include/*.h
     lib/llama_wrapper.so   the same file under the name the reference's
                            llama_cpp_bindings.py:18-35 looks for
+    lib/qwen3_cp_server    native code-predictor server over the cp_* ABI (the reference's
+                           code_predictor_cpp / code_predictor_ggml binaries)
 """
 from __future__ import annotations
 
@@ -64,6 +66,14 @@ def build(force: bool = False, verbose: bool = False, timeline: bool = False) ->
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     if not timeline:
+        # the native code-predictor server (the reference's code_predictor_cpp / code_predictor_ggml binaries)
+        srv_src = os.path.join(CSRC, "cp_server_main.cpp")
+        srv = os.path.join(LIB, "qwen3_cp_server")
+        if force or not _newer(srv, [srv_src, out]):
+            cmd = ["g++", "-O2", "-std=c++17", srv_src, "-o", srv, "-L" + LIB, "-lqwen3tts", "-Wl,-rpath,$ORIGIN"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
         alias = os.path.join(LIB, "llama_wrapper.so")
         if not os.path.exists(alias) or os.path.getmtime(alias) < os.path.getmtime(out):
             shutil.copyfile(out, alias)

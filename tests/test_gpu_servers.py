@@ -131,3 +131,51 @@ def test_batch_server_matches_single_utterance_path(gpu_lib, packs, tmp_path):
     srv._running = False
     th.join(timeout=5)
     srv.close()
+
+
+def test_native_cp_server_binary(gpu_lib, packs, tmp_path):
+    """The native code-predictor server (csrc/cp_server_main.cpp, the reference's code_predictor_cpp /
+    code_predictor_ggml binaries): 4100 bytes in, 60 bytes out, one connection per frame; greedy codes equal
+    the library's cp_predict; SIGTERM stops it and removes the socket."""
+    import signal
+    import socket
+    import subprocess
+    from qwen3_tts_axera_russian_amd import LIB_DIR, protocol as P
+    from qwen3_tts_axera_russian_amd.llama_cpp_bindings import CodePredictor
+    main, _, cfg = packs
+    exe = os.path.join(LIB_DIR, "qwen3_cp_server")
+    assert os.path.exists(exe), "build it with python -m qwen3_tts_axera_russian_amd.build"
+    sock = str(tmp_path / "cp_native.sock")
+    proc = subprocess.Popen([exe, "--weights", main, "--socket", sock, "--temperature", "0"],
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    try:
+        _wait(sock)
+        cp = CodePredictor(main, max_batch=1)
+        rng = np.random.default_rng(23)
+        for i in range(5):
+            hidden = rng.standard_normal(1024).astype(np.float32)
+            code0 = int(rng.integers(0, 2048)) if i else 100
+            s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            s.connect(sock)
+            s.sendall(P.pack_cp_request(hidden, code0))
+            raw = P.recv_exact(s, 60)
+            assert P.recv_exact(s, 1) == b""          # the server closes after the reply
+            s.close()
+            got = np.frombuffer(raw, dtype="<i4")
+            assert got.shape == (15,)
+            np.testing.assert_array_equal(got, np.asarray(cp.predict(hidden, code0)))
+        cp.destroy()
+        # a short request is dropped without a reply, the server keeps serving
+        s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        s.connect(sock)
+        s.sendall(b"\0" * 100)
+        s.shutdown(socket.SHUT_WR)
+        assert s.recv(4) == b""
+        s.close()
+    finally:
+        proc.send_signal(signal.SIGTERM)
+        out, _ = proc.communicate(timeout=20)
+    text = out.decode(errors="replace")
+    assert proc.returncode == 0, text
+    assert "warmup result" in text and "Server stopped." in text
+    assert not os.path.exists(sock)
