@@ -44,6 +44,10 @@ def main():
     ap.add_argument("--output", default="output.wav")
     ap.add_argument("--token_ids", default=None)
     ap.add_argument("--daemon", action="store_true")
+    ap.add_argument("--cp_backend", choices=["auto", "native", "python"], default=os.environ.get("CP_BACKEND", "auto"),
+                    help="code-predictor server: the native binary (lib/qwen3_cp_server) when built, else the Python one "
+                         "(the reference's launcher picks GGML > C++ > Python the same way, launch_qwen3_tts.sh:109-115)")
+    ap.add_argument("--cp_temperature", type=float, default=float(os.environ.get("CP_TEMPERATURE", "0.1")))
     a = ap.parse_args()
     env = dict(os.environ, HIP_VISIBLE_DEVICES=str(a.gpu), PYTHONUNBUFFERED="1")
     sfx = f"_gpu{a.gpu}"
@@ -59,6 +63,12 @@ def main():
         "cp": [sys.executable, "-m", mod + "code_predictor_server", "--model", a.weights, "--socket", socks["cp"]],
         "voc": [sys.executable, "-m", mod + "vocoder_server", "--model", a.vocoder, "--socket", socks["voc"]],
     }
+    native_cp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "qwen3_cp_server")
+    if a.cp_backend == "native" or (a.cp_backend == "auto" and os.path.exists(native_cp)):
+        if not os.path.exists(native_cp):
+            raise SystemExit(f"{native_cp} is not built (python -m qwen3_tts_axera_russian_amd.build)")
+        cmds["cp"] = [native_cp, "--weights", a.weights, "--socket", socks["cp"], "--temperature", str(a.cp_temperature),
+                      "--top_k", str(a.top_k)]
     procs = {}
 
     def cleanup(*_):
