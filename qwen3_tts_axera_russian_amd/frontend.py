@@ -94,3 +94,28 @@ def feedback_embedding(code_0, codes_1_15, codec_embedding, cp_codec_embeddings,
     if tts_pad_embed is not None:
         buf += tts_pad_embed
     return buf
+
+
+def load_text_front_end(model_path=None, embeddings_dir=None, cfg=None):
+    """-> (cfg, TextFrontEnd).  Tables from the reference's own `embeddings/` directory when given
+    (text_embedding.npy, text_projection_linear_fc{1,2}_{weight,bias}.npy, codec_embedding.npy:
+    scripts/extract_embeddings.py:47-66, loaded as dual_npu/llamacpp_talker_server.py:79-93 does), else
+    from the `text.*` / `talker.codec_embedding` tensors of a Q3TTSW1 container."""
+    import os
+
+    import numpy as np
+
+    from .weights import ModelConfig, read_pack
+    if embeddings_dir:
+        e = lambda n: np.load(os.path.join(embeddings_dir, n), mmap_mode="r")
+        f32 = lambda n: np.asarray(e(n), dtype=np.float32)
+        cfg = cfg or ModelConfig()
+        table = e("text_embedding.npy")             # 1.2 GB in the real model: stays memory-mapped, rows are gathered
+        return cfg, TextFrontEnd(cfg, table, f32("text_projection_linear_fc1_weight.npy"),
+                                 f32("text_projection_linear_fc1_bias.npy"), f32("text_projection_linear_fc2_weight.npy"),
+                                 f32("text_projection_linear_fc2_bias.npy"), f32("codec_embedding.npy"))
+    meta, t = read_pack(model_path)
+    cfg = cfg or ModelConfig.from_meta(meta)
+    g = lambda n: np.asarray(t[n], dtype=np.float32)
+    return cfg, TextFrontEnd(cfg, t["text.embedding"], g("text.fc1.weight"), g("text.fc1.bias"), g("text.fc2.weight"),
+                             g("text.fc2.bias"), g("talker.codec_embedding"))

@@ -4,7 +4,7 @@
 Same socket protocol, CLI flags, sampling heuristics and KV-prefix-cache behaviour; the talker runs
 through the HIP build of the wrapper_* ABI (llama_cpp_bindings.LlamaCppModel) instead of llama.cpp,
 and the codec head is a device GEMV.  Tables (text embedding, projection MLP, codec embedding) come
-from the same Q3TTSW1 container as the talker weights.
+from the reference's own embeddings/ directory (--embeddings) or from the Q3TTSW1 container of --model.
 
     python -m qwen3_tts_axera_russian_amd.llamacpp_talker_server --model qwen3tts.q3w \
         [--tokenizer /path/to/local/tokenizer_dir] --socket /tmp/qwen3_talker.sock
@@ -24,9 +24,9 @@ import time
 import numpy as np
 
 from . import protocol as P
-from .frontend import TalkerSampler, TextFrontEnd
+from .frontend import TalkerSampler, load_text_front_end
 from .llama_cpp_bindings import LlamaCppModel
-from .weights import ModelConfig, read_pack
+
 
 
 class Qwen3TTSTalkerServer:
@@ -34,13 +34,10 @@ class Qwen3TTSTalkerServer:
                  top_k=50, max_tokens=200, n_threads=4, kv_cache_dir="/tmp", tokenizer=None, n_ctx=512,
                  install_signal_handlers=True):
         self.socket_path, self.max_tokens, self.kv_cache_dir = socket_path, max_tokens, kv_cache_dir
-        meta, t = read_pack(model_path)
-        self.cfg = ModelConfig.from_meta(meta)
-        f32 = lambda n: np.asarray(t[n], dtype=np.float32)
         print("Loading embeddings...")
-        self.codec_embedding = f32("talker.codec_embedding")
-        self.front = TextFrontEnd(self.cfg, t["text.embedding"], f32("text.fc1.weight"), f32("text.fc1.bias"),
-                                  f32("text.fc2.weight"), f32("text.fc2.bias"), self.codec_embedding)
+        # the reference's own embeddings/ directory (llamacpp_talker_server.py:79-93) or the container's text.* tensors
+        self.cfg, self.front = load_text_front_end(model_path, embeddings_dir)
+        self.codec_embedding = self.front.codec
         self.tts_pad_embed = self.front.tts_pad_embed
         self.sampler = TalkerSampler(self.cfg.codec_eos, self.cfg.cp_vocab, temperature, top_k)
         self.tokenizer = None
@@ -173,8 +170,8 @@ class Qwen3TTSTalkerServer:
 
 def main():
     ap = argparse.ArgumentParser(description="Qwen3-TTS Talker Server (MI355X / HIP)")
-    ap.add_argument("--model", required=True, help="Q3TTSW1 weight container (talker.*, text.*)")
-    ap.add_argument("--embeddings", default=None, help="accepted for CLI compatibility; tables come from --model")
+    ap.add_argument("--model", required=True, help="Q3TTSW1 container, or the re-keyed talker model.safetensors / its directory")
+    ap.add_argument("--embeddings", default=None, help="the reference's embeddings/ directory of .npy tables (default: the text.* tensors of --model)")
     ap.add_argument("--socket", default="/tmp/qwen3_talker.sock")
     ap.add_argument("--temperature", type=float, default=0.8)
     ap.add_argument("--top_k", type=int, default=50)

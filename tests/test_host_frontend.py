@@ -61,3 +61,28 @@ def test_wire_messages_are_byte_identical_to_the_reference_client(golden):
     assert P.pack_sentinel(P.SENTINEL_DONE) == struct.pack("<i", -1)
     msg = json.loads(P.pack_talker_request("x", "english", [1, 2])[4:].decode())
     assert msg["token_ids"] == [1, 2]
+
+
+def test_text_front_end_from_the_reference_embeddings_directory(tmp_path):
+    """The talker server's tables from the reference's own embeddings/ directory of .npy files
+    (scripts/extract_embeddings.py:47-66) give the same prefix rows as the container's text.* tensors."""
+    import numpy as np
+    from qwen3_tts_axera_russian_amd import weights as W
+    from qwen3_tts_axera_russian_amd.frontend import load_text_front_end
+    cfg = W.tiny_config(1, 1, text_vocab=300)
+    cfg.text_dim = 48
+    pack = str(tmp_path / "t.q3w")
+    W.write_synthetic(pack, cfg, seed=5, parts=("talker", "text"))
+    _, t = W.read_pack(pack)
+    emb = tmp_path / "embeddings"
+    emb.mkdir()
+    np.save(emb / "text_embedding.npy", np.asarray(t["text.embedding"], np.float32))
+    for k in ("fc1", "fc2"):
+        np.save(emb / f"text_projection_linear_{k}_weight.npy", np.asarray(t[f"text.{k}.weight"], np.float32))
+        np.save(emb / f"text_projection_linear_{k}_bias.npy", np.asarray(t[f"text.{k}.bias"], np.float32))
+    np.save(emb / "codec_embedding.npy", np.asarray(t["talker.codec_embedding"], np.float32))
+    _, a = load_text_front_end(pack, None)
+    _, b = load_text_front_end(None, str(emb), cfg=cfg)
+    ids = [5, 17, 200, 33, 41]
+    np.testing.assert_array_equal(a.build_prefix(ids), b.build_prefix(ids))
+    np.testing.assert_array_equal(a.tts_pad_embed, b.tts_pad_embed)
