@@ -8,6 +8,7 @@ CLI.  `--token_ids` (extension) sends pre-tokenised text.
 from __future__ import annotations
 
 import argparse
+import os
 import socket
 import struct
 import threading
@@ -27,10 +28,20 @@ VOC_CHUNK_SIZE = 64
 
 class Qwen3TTSClient:
     def __init__(self, talker_socket="/tmp/qwen3_talker.sock", cp_socket="/tmp/qwen3_cp.sock",
-                 voc_socket="/tmp/qwen3_voc.sock", weights=None):
+                 voc_socket="/tmp/qwen3_voc.sock", weights=None, embeddings_dir=None, cp_dir=None):
+        """Tables of the feedback sum: from a Q3TTSW1 container (`weights`), or, like the reference's client
+        (tts_client.py:39-76), from its embeddings/ directory (.npy) and code-predictor directory (.npz)."""
         self.talker_socket, self.cp_socket, self.voc_socket = talker_socket, cp_socket, voc_socket
         self.codec_embedding = self.cp_codec_embeddings = self.tts_pad_embed = None
-        if weights:
+        if embeddings_dir:
+            from .frontend import load_text_front_end
+            _, fe = load_text_front_end(None, embeddings_dir)
+            self.codec_embedding = np.asarray(fe.codec, dtype=np.float32)
+            self.tts_pad_embed = fe.tts_pad_embed
+            if cp_dir:
+                w = np.load(os.path.join(cp_dir, "code_predictor_weights.npz"))
+                self.cp_codec_embeddings = [w[f"codec_emb_{i}"].astype(np.float32) for i in range(P.NUM_CP_CODES)]
+        elif weights:
             meta, t = read_pack(weights)
             cfg = ModelConfig.from_meta(meta)
             f32 = lambda n: np.asarray(t[n], dtype=np.float32)
@@ -122,13 +133,17 @@ def main():
     ap.add_argument("--talker_socket", default="/tmp/qwen3_talker.sock")
     ap.add_argument("--cp_socket", default="/tmp/qwen3_cp.sock")
     ap.add_argument("--voc_socket", default="/tmp/qwen3_voc.sock")
-    ap.add_argument("--weights", required=True, help="Q3TTSW1 container (tables for the feedback embedding)")
+    ap.add_argument("--weights", default=None, help="Q3TTSW1 container (tables for the feedback embedding)")
+    ap.add_argument("--embeddings_dir", default=None, help="the reference's embeddings/ directory (instead of --weights)")
+    ap.add_argument("--cp_dir", default=None, help="the reference's code-predictor directory (code_predictor_weights.npz)")
     ap.add_argument("--token_ids", default=None, help="comma-separated text token ids (skips the tokenizer)")
     ap.add_argument("--streaming", action="store_true")
     a = ap.parse_args()
     text = a.text or a.text_flag or "Привет, как дела? Сегодня хорошая погода для прогулки."
     ids = [int(x) for x in a.token_ids.split(",")] if a.token_ids else None
-    Qwen3TTSClient(a.talker_socket, a.cp_socket, a.voc_socket, a.weights).synthesize(
+    if not a.weights and not (a.embeddings_dir and a.cp_dir):
+        ap.error("give --weights, or --embeddings_dir and --cp_dir")
+    Qwen3TTSClient(a.talker_socket, a.cp_socket, a.voc_socket, a.weights, a.embeddings_dir, a.cp_dir).synthesize(
         text, a.language, a.output, streaming=a.streaming, token_ids=ids)
 
 

@@ -86,3 +86,43 @@ def test_text_front_end_from_the_reference_embeddings_directory(tmp_path):
     ids = [5, 17, 200, 33, 41]
     np.testing.assert_array_equal(a.build_prefix(ids), b.build_prefix(ids))
     np.testing.assert_array_equal(a.tts_pad_embed, b.tts_pad_embed)
+
+
+def test_client_tables_from_the_reference_directories(tmp_path):
+    """The client's feedback tables from the reference's embeddings/ + code-predictor directories
+    (tts_client.py:39-76) equal the container's."""
+    import numpy as np
+    from qwen3_tts_axera_russian_amd import weights as W
+    from qwen3_tts_axera_russian_amd.tts_client import Qwen3TTSClient
+    # the reference client hard-codes tts_pad = 151671: its tables at the real ids, with a sparse text table
+    pack = str(tmp_path / "t.q3w")
+    full = W.ModelConfig(talker_layers=1, cp_layers=1, text_dim=32)
+    t = W.make_synthetic(full, seed=9, parts=("cp",))
+    rng = np.random.default_rng(1)
+    text = np.zeros((full.text_vocab, 32), np.float32)
+    text[full.tts_pad:full.tts_eos + 1] = rng.standard_normal((3, 32)).astype(np.float32)
+    for n in (full.im_start, full.assistant, full.newline):
+        text[n] = rng.standard_normal(32).astype(np.float32)
+    t["text.embedding"] = text
+    t["text.fc1.weight"] = (0.2 * rng.standard_normal((32, 32))).astype(np.float32)
+    t["text.fc1.bias"] = (0.1 * rng.standard_normal(32)).astype(np.float32)
+    t["text.fc2.weight"] = (0.2 * rng.standard_normal((1024, 32))).astype(np.float32)
+    t["text.fc2.bias"] = (0.1 * rng.standard_normal(1024)).astype(np.float32)
+    t["talker.codec_embedding"] = (0.1 * rng.standard_normal((3072, 1024))).astype(np.float32)
+    W.write_pack(pack, full.meta(), t)
+    emb, cp = tmp_path / "embeddings", tmp_path / "code_predictor"
+    emb.mkdir()
+    cp.mkdir()
+    np.save(emb / "text_embedding.npy", text)
+    for k in ("fc1", "fc2"):
+        np.save(emb / f"text_projection_linear_{k}_weight.npy", t[f"text.{k}.weight"])
+        np.save(emb / f"text_projection_linear_{k}_bias.npy", t[f"text.{k}.bias"])
+    np.save(emb / "codec_embedding.npy", t["talker.codec_embedding"])
+    np.savez(cp / "code_predictor_weights.npz", **{f"codec_emb_{g}": np.asarray(t[f"cp.codec_emb.{g}"], np.float32) for g in range(15)})
+    a = Qwen3TTSClient(weights=pack)
+    b = Qwen3TTSClient(embeddings_dir=str(emb), cp_dir=str(cp))
+    np.testing.assert_array_equal(a.tts_pad_embed, b.tts_pad_embed)
+    np.testing.assert_array_equal(a.codec_embedding, b.codec_embedding)
+    assert len(b.cp_codec_embeddings) == 15
+    for x, y in zip(a.cp_codec_embeddings, b.cp_codec_embeddings):
+        np.testing.assert_array_equal(x, y)
