@@ -75,7 +75,7 @@ class CodePredictorServer:
 
 def main():
     ap = argparse.ArgumentParser(description="Qwen3-TTS Code Predictor Server (MI355X / HIP)")
-    ap.add_argument("--model_dir", "--model", dest="model", required=True, help="Q3TTSW1 container (cp.*, talker.codec_embedding)")
+    ap.add_argument("--model_dir", "--model", dest="model", required=True, help="the reference's model directory (code_predictor_weights.npz, with --embeddings_dir for codec_embedding.npy) or a Q3TTSW1 container")
     ap.add_argument("--embeddings_dir", default=None)
     ap.add_argument("--socket", default="/tmp/qwen3_cp.sock")
     ap.add_argument("--temperature", type=float, default=0.1)
