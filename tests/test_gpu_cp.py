@@ -123,3 +123,33 @@ def test_cp_stochastic_sampling_distribution(gpu_lib, setup):
     g = cp.predict_batch(H[:1], C0[:1], temperature=0.0)
     assert list(g[0]) == [int(x) for x in codes] or margins.min() < 1e-4
     cp.destroy()
+
+
+def test_cp_load_from_the_reference_directories(gpu_lib, setup, tmp_path):
+    """cp_load on the reference's own files -- --model_dir/code_predictor_weights.npz (written by np.savez as
+    scripts/export_code_predictor_weights.py:76 does, f32) + --embeddings_dir/codec_embedding.npy -- parsed natively
+    (csrc/q3_formats.cpp) gives the codes of the container holding the same values."""
+    path, cfg, tensors, ref = setup
+    model_dir, emb_dir = tmp_path / "code_predictor", tmp_path / "embeddings"
+    model_dir.mkdir()
+    emb_dir.mkdir()
+    w = {}
+    for i in range(cfg.cp_layers):
+        for p in ("input_ln", "q_proj", "k_proj", "v_proj", "o_proj", "q_norm", "k_norm", "post_ln", "gate_proj",
+                  "up_proj", "down_proj"):
+            w[f"layer_{i}_{p}"] = np.asarray(tensors[f"cp.layers.{i}.{p}"], dtype=np.float32)
+    w["final_norm"] = np.asarray(tensors["cp.norm"], dtype=np.float32)
+    for g in range(cfg.cp_groups):
+        w[f"codec_emb_{g}"] = np.asarray(tensors[f"cp.codec_emb.{g}"], dtype=np.float32)
+        w[f"lm_head_{g}"] = np.asarray(tensors[f"cp.lm_head.{g}"], dtype=np.float32)
+    np.savez(model_dir / "code_predictor_weights.npz", **w)
+    np.save(emb_dir / "codec_embedding.npy", np.asarray(tensors["talker.codec_embedding"], dtype=np.float32))
+    a = CodePredictor(path, max_batch=1)
+    b = CodePredictor(str(model_dir), str(emb_dir), max_batch=1)
+    rng = np.random.default_rng(41)
+    for _ in range(3):
+        hidden = rng.standard_normal(1024).astype(np.float32)
+        code0 = int(rng.integers(0, 2048))
+        np.testing.assert_array_equal(np.asarray(b.predict(hidden, code0)), np.asarray(a.predict(hidden, code0)))
+    a.destroy()
+    b.destroy()
