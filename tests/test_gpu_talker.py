@@ -158,3 +158,44 @@ def test_long_context_beyond_the_reference_n_ctx(gpu_lib, tiny):
     print("long-context rel errs:", ["%.2e" % e for e in errs])
     assert max(errs) < TOL and llm.pos == n + 4
     llm.destroy()
+
+
+def test_load_talker_from_rekeyed_safetensors(gpu_lib, tiny, tmp_path):
+    """wrapper_load_model on the file the reference's converter writes before its GGUF step (re-keyed
+    Qwen3ForCausalLM talker, BF16, embed_tokens / lm_head padded to the text vocabulary:
+    scripts/extract_talker_as_qwen3.py:53-71), parsed natively: same hidden states as the container holding
+    the same values."""
+    torch = pytest.importorskip("torch")
+    from safetensors.torch import save_file
+    path, cfg, tensors = tiny
+    hf = {"input_ln": "input_layernorm.weight", "q_proj": "self_attn.q_proj.weight", "k_proj": "self_attn.k_proj.weight",
+          "v_proj": "self_attn.v_proj.weight", "o_proj": "self_attn.o_proj.weight", "q_norm": "self_attn.q_norm.weight",
+          "k_norm": "self_attn.k_norm.weight", "post_ln": "post_attention_layernorm.weight",
+          "gate_proj": "mlp.gate_proj.weight", "up_proj": "mlp.up_proj.weight", "down_proj": "mlp.down_proj.weight"}
+    t = {}
+    for i in range(cfg.talker_layers):
+        for p, k in hf.items():
+            a = np.asarray(tensors[f"talker.layers.{i}.{p}"])
+            # fp16 matrices travel as F16 (exact); norm vectors as F32
+            t[f"model.layers.{i}.{k}"] = torch.from_numpy(np.array(a, dtype=a.dtype))
+    t["model.norm.weight"] = torch.from_numpy(np.array(tensors["talker.norm"], dtype=np.float32))
+    emb = np.zeros((4000, 1024), np.float32)
+    emb[:3072] = np.asarray(tensors["talker.codec_embedding"], dtype=np.float32)
+    t["model.embed_tokens.weight"] = torch.from_numpy(emb)
+    head = np.zeros((4000, 1024), np.float16)
+    head[:3072] = np.asarray(tensors["talker.codec_head"], dtype=np.float16)
+    t["lm_head.weight"] = torch.from_numpy(head)
+    d = tmp_path / "talker_as_qwen3"
+    d.mkdir()
+    save_file(t, str(d / "model.safetensors"), metadata={"format": "pt"})
+    a = LlamaCppModel(path, n_ctx=64)
+    b = LlamaCppModel(str(d), n_ctx=64)           # the directory, as the reference's scripts leave it
+    rng = np.random.default_rng(3)
+    prefix = _prefix(rng, 11)
+    np.testing.assert_array_equal(b.get_hidden(prefix, keep_history=0), a.get_hidden(prefix, keep_history=0))
+    fb = _prefix(rng, 1)
+    hb, ha = b.get_hidden(fb, keep_history=1), a.get_hidden(fb, keep_history=1)
+    np.testing.assert_array_equal(hb, ha)
+    np.testing.assert_array_equal(b.codec_head(hb), a.codec_head(ha))
+    a.destroy()
+    b.destroy()
