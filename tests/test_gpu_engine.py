@@ -142,3 +142,46 @@ def test_full_depth_frame_graph_speed_guard(gpu_lib):
     print("full-depth frame graph:", ms, "ms per frame at 4 utterances")
     np.testing.assert_array_equal(outs[0], outs[1])
     assert ms < 9.0
+
+
+def test_engine_loads_the_hf_snapshot_layout(gpu_lib, world, tmp_path):
+    """q3e_create on a directory holding the HF checkpoint's model.safetensors (talker.model.layers.*,
+    talker.code_predictor.*: the keys scripts/extract_embeddings.py:47-98 reads), parsed natively: the frame loop
+    produces the codes of the container holding the same values."""
+    torch = pytest.importorskip("torch")
+    from safetensors.torch import save_file
+    path, cfg, tensors, cpu = world
+    hf = {"input_ln": "input_layernorm.weight", "q_proj": "self_attn.q_proj.weight", "k_proj": "self_attn.k_proj.weight",
+          "v_proj": "self_attn.v_proj.weight", "o_proj": "self_attn.o_proj.weight", "q_norm": "self_attn.q_norm.weight",
+          "k_norm": "self_attn.k_norm.weight", "post_ln": "post_attention_layernorm.weight",
+          "gate_proj": "mlp.gate_proj.weight", "up_proj": "mlp.up_proj.weight", "down_proj": "mlp.down_proj.weight"}
+    tt = lambda n: torch.from_numpy(np.array(tensors[n]))
+    t = {}
+    for i in range(cfg.talker_layers):
+        for p, k in hf.items():
+            t[f"talker.model.layers.{i}.{k}"] = tt(f"talker.layers.{i}.{p}")
+    for i in range(cfg.cp_layers):
+        for p, k in hf.items():
+            t[f"talker.code_predictor.model.layers.{i}.{k}"] = tt(f"cp.layers.{i}.{p}")
+    t["talker.model.norm.weight"] = tt("talker.norm")
+    t["talker.code_predictor.model.norm.weight"] = tt("cp.norm")
+    t["talker.model.codec_embedding.weight"] = tt("talker.codec_embedding")
+    t["talker.codec_head.weight"] = tt("talker.codec_head")
+    for g in range(cfg.cp_groups):
+        t[f"talker.code_predictor.model.codec_embedding.{g}.weight"] = tt(f"cp.codec_emb.{g}")
+        t[f"talker.code_predictor.lm_head.{g}.weight"] = tt(f"cp.lm_head.{g}")
+    snap = tmp_path / "snapshot"
+    snap.mkdir()
+    save_file(t, str(snap / "model.safetensors"), metadata={"format": "pt"})
+    rng = np.random.default_rng(19)
+    prefixes = _prefixes(rng, [14, 21])
+    pad = (0.05 * rng.standard_normal(1024)).astype(np.float32)
+    outs = []
+    for src in (path, str(snap)):
+        eng = FrameEngine(src, max_batch=2, n_ctx=96, max_frames=12)
+        eng.set_pad_embed(pad)
+        eng.start(prefixes, [5, 12], ignore_eos=True, max_frames=12)
+        assert eng.run(12) == 12
+        outs.append(eng.codes()[0].copy())
+        eng.destroy()
+    np.testing.assert_array_equal(outs[0], outs[1])
