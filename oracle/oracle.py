@@ -72,10 +72,17 @@ def lib():
         L.orc_cp_predict.argtypes = [ctypes.POINTER(_Stack), c_float_p, ctypes.c_int, ctypes.POINTER(c_float_p),
                                      ctypes.POINTER(c_float_p), ctypes.c_int, ctypes.c_int, c_float_p,
                                      ctypes.c_int, c_int_p, c_int_p, c_float_p, c_float_p]
+        L.orc_set_exact.argtypes = [ctypes.c_int]
         L.orc_matvec.argtypes = [c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int]
         L.orc_rmsnorm_round.argtypes = [c_float_p, c_float_p, ctypes.c_float, ctypes.c_int, c_float_p]
         _LIB = L
     return _LIB
+
+
+def set_exact(on: bool) -> None:
+    """Exact mode = plain fp32 Qwen3 layer (no fp16 rounding of activations / K/V): the form that is
+    compared with transformers' Qwen3Model (tests/golden/make_hf_golden.py)."""
+    lib().orc_set_exact(1 if on else 0)
 
 
 def fp(a: np.ndarray):

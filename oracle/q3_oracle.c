@@ -82,6 +82,12 @@ float orc_round_f16(float x) { return h2f(f2h_sat(x)); }
 void orc_round_f16_array(const float* x, float* y, long n) {
     for (long i = 0; i < n; i++) y[i] = orc_round_f16(x[i]);
 }
+/* Exact mode: activations and K/V are NOT rounded to fp16 (weights keep the values they were given).
+ * This is the plain fp32 Qwen3 layer, the form that tests/golden/make_hf_golden.py compares with
+ * transformers' Qwen3Model; the default (rounded) mode is the device's numerics contract. */
+static int g_exact = 0;
+void orc_set_exact(int on) { g_exact = on; }
+static float act_round(float x) { return g_exact ? x : orc_round_f16(x); }
 
 /* RoPE tables exactly as the HIP library builds them on the host (q3_model.hip): float32
  * arithmetic like the HF rotary embedding. */
@@ -112,7 +118,7 @@ static void rmsnorm_round(const float* h, const float* gamma, float eps, int H, 
     double ss = 0.0;
     for (int k = 0; k < H; k++) ss += (double)h[k] * h[k];
     const float inv = 1.0f / sqrtf((float)ss / (float)H + eps);
-    for (int k = 0; k < H; k++) x16[k] = orc_round_f16((h[k] * inv) * gamma[k]);
+    for (int k = 0; k < H; k++) x16[k] = act_round((h[k] * inv) * gamma[k]);
 }
 
 static void head_norm_rope(float* x, const float* gamma, float eps, int D, const float* cs, const float* sn) {
@@ -157,8 +163,8 @@ static void token_forward(const orc_stack* st, float* kc, float* vc, int n_ctx, 
         for (int gk = 0; gk < NKV; gk++) {
             head_norm_rope(kn + gk * D, L->k_norm, st->eps, D, cs, sn);
             for (int i = 0; i < D; i++) {
-                kl[((size_t)gk * n_ctx + pos) * D + i] = orc_round_f16(kn[gk * D + i]);
-                vl[((size_t)gk * n_ctx + pos) * D + i] = orc_round_f16(vn[gk * D + i]);
+                kl[((size_t)gk * n_ctx + pos) * D + i] = act_round(kn[gk * D + i]);
+                vl[((size_t)gk * n_ctx + pos) * D + i] = act_round(vn[gk * D + i]);
             }
         }
         for (int hd = 0; hd < NH; hd++) {
@@ -184,7 +190,7 @@ static void token_forward(const orc_stack* st, float* kc, float* vc, int n_ctx, 
                 const float p = sc[t];
                 for (int i = 0; i < D; i++) oh[i] += p * vr[i];
             }
-            for (int i = 0; i < D; i++) oh[i] = orc_round_f16(oh[i] / sum);
+            for (int i = 0; i < D; i++) oh[i] = act_round(oh[i] / sum);
         }
         matvec(L->o, att, y, H, NH * D);
         for (int k = 0; k < H; k++) h[k] += y[k];
@@ -193,7 +199,7 @@ static void token_forward(const orc_stack* st, float* kc, float* vc, int n_ctx, 
         matvec(L->up, x16, u, F, H);
         for (int j = 0; j < F; j++) {
             const float sg = g[j] / (1.0f + expf(-g[j]));
-            g[j] = orc_round_f16(sg * u[j]);
+            g[j] = act_round(sg * u[j]);
         }
         matvec(L->down, g, y, H, F);
         for (int k = 0; k < H; k++) h[k] += y[k];
@@ -236,7 +242,7 @@ int orc_forward(const orc_stack* st, float* kc, float* vc, int n_ctx, const floa
 /* logits[V] = head[V][H] . fp16(hidden)  (llamacpp_talker_server.py:165; code_predictor_server.py:129) */
 void orc_head(const float* head, int V, int H, const float* hidden, float* logits) {
     float* x = (float*)malloc(sizeof(float) * H);
-    for (int k = 0; k < H; k++) x[k] = orc_round_f16(hidden[k]);
+    for (int k = 0; k < H; k++) x[k] = act_round(hidden[k]);
     matvec(head, x, logits, V, H);
     free(x);
 }
