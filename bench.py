@@ -272,9 +272,9 @@ def main():
     from qwen3_tts_axera_russian_amd import hiplib
     from qwen3_tts_axera_russian_amd.engine import FrameEngine
     lib = hiplib.load()
-    if lib.q3t_device_count() <= 0:
+    if lib.q3_device_count() <= 0:
         raise SystemExit("bench.py: no HIP device -- the HIP library is the only compute path")
-    lib.q3_set_device(local_rank % lib.q3t_device_count())
+    lib.q3_set_device(local_rank % lib.q3_device_count())
 
     sync_all = R.sync_all  # engine calls are synchronous (every q3e_run ends with a stream sync)
 

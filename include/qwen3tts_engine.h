@@ -21,6 +21,12 @@
 extern "C" {
 #endif
 
+/* Number of visible HIP devices (0 = none: every loader of this library then returns NULL; there is no
+ * CPU path), and selection of the device used by handles created afterwards (one process per GPU:
+ * the per-GPU launcher sets HIP_VISIBLE_DEVICES, a torchrun rank passes LOCAL_RANK). */
+int q3_device_count(void);
+int q3_set_device(int device);
+
 /* weights: Q3TTSW1 container with talker.* and cp.*.  max_batch utterances at once, n_ctx talker
  * positions per utterance (prefix + frames), max_frames frames kept per utterance. */
 void* q3e_create(const char* weights, int max_batch, int n_ctx, int max_frames);
@@ -29,10 +35,19 @@ void q3e_free(void* e);
 /* Sampling.  Defaults are greedy (temperature 0 = the reference's --temperature 0 limit).  With
  * temperature > 1e-6 the device draws from top-k / temperature (/ top-p for the talker) like
  * llamacpp_talker_server.py:191-206 and code_predictor_server.py:87-92; the generator is counter based
- * (seed, utterance, frame, group), so a run is reproducible for a seed but not bit-compatible with
- * numpy's or mt19937's streams. */
+ * (seed, request, utterance, frame, group): the first q3e_start after this call draws from `seed` itself,
+ * every later one from a stream derived from (seed, request index), so a server replays nothing across
+ * requests, a run is reproducible for a seed, and nothing is bit-compatible with numpy's or mt19937's streams.
+ * top_k <= 0 (or >= the vocabulary) keeps every entry, as in the reference. */
 int q3e_set_sampling(void* e, float talker_temperature, int talker_top_k, float talker_top_p,
                      float cp_temperature, int cp_top_k, uint64_t seed);
+
+/* Teacher forcing: forced[f][b][16] (f < n_frames, b < B of the batch just started; entries < 0 = free-running).
+ * Every decision the device takes is still recorded in the codes array, but the ids that are FED BACK (the
+ * repetition window, the code predictor's inputs, the feedback embedding) are the forced ones -- continuing a
+ * given codec prompt, and what the parity tests use to grade every decision of a run against the oracle, not only
+ * those before the first near-tie.  Call after q3e_start; NULL switches it off; the next q3e_start resets it. */
+int q3e_set_forced_codes(void* e, const int32_t* forced, int n_frames);
 
 /* Split every frame step into n (1..8) independent row groups that run as parallel branches of the
  * captured graph: hides per-kernel launch latency behind the other groups' work at the price of
@@ -52,7 +67,8 @@ int q3e_start(void* e, int B, const float* prefix, const int32_t* n_rows, const 
               int ignore_eos, int max_frames);
 
 /* Generate up to n_frames more frames for the whole batch (returns early once every utterance
- * has finished).  Returns the number of frame steps executed, <0 on error. */
+ * has finished; never steps past the max_frames given to q3e_start: 0 when none is left).  Returns the
+ * number of frame steps executed, <0 on error. */
 int q3e_run(void* e, int n_frames);
 
 /* GPU time of the last q3e_run / q3e_start in milliseconds (HIP events on the engine's stream). */

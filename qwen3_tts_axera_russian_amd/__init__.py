@@ -7,3 +7,4 @@ import os
 
 LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libqwen3tts.so")
+TEST_LIB_PATH = os.path.join(LIB_DIR, "libqwen3tts_test.so")   # kernel-level hooks for tests/ and bench.py only

@@ -3,7 +3,9 @@
     python -m qwen3_tts_axera_russian_amd.build
 
 Outputs (git-ignored, shipped to the GPU box by gpurun):
-    lib/libqwen3tts.so     every C-ABI symbol of include/*.h
+    lib/libqwen3tts.so     every C-ABI symbol of include/*.h (the product; no test hooks inside)
+    lib/libqwen3tts_test.so  kernel-level hooks for tests/ and bench.py (csrc/q3_test_api.hip), linked
+                           against the product library
     lib/llama_wrapper.so   the same file under the name the reference's
                            llama_cpp_bindings.py:18-35 looks for
     lib/qwen3_cp_server    native code-predictor server over the cp_* ABI (the reference's
@@ -20,7 +22,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib")
 SOURCES = ["q3_common.cpp", "q3_formats.cpp", "q3_kernels.hip", "q3_model.hip", "q3_talker_api.hip", "q3_cp_api.hip",
-           "q3_engine.hip", "q3_voc.hip", "q3_test_api.hip"]
+           "q3_engine.hip", "q3_voc.hip"]
+TEST_SOURCES = ["q3_test_api.hip"]
 ARCH = os.environ.get("Q3_OFFLOAD_ARCH", "gfx950")
 # kernarg preload: the leading scalar kernel arguments arrive in SGPRs at wave launch (gfx940+)
 EXTRA = os.environ.get("Q3_EXTRA_HIPCC_FLAGS", "-mllvm -amdgpu-kernarg-preload-count=16").split()
@@ -62,6 +65,16 @@ def build(force: bool = False, verbose: bool = False, timeline: bool = False) ->
             list(pool.map(run, jobs))
     if force or not _newer(out, objs):
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs + ["-lz"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    # test hooks: a separate library over the product one (tests/ and bench.py only)
+    tout = os.path.join(LIB, f"libqwen3tts_test{tag}.so")
+    tsrcs = [os.path.join(CSRC, s) for s in TEST_SOURCES]
+    if force or not _newer(tout, tsrcs + hdrs + [out]):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip"] + tsrcs + \
+              ["-o", tout, "-Wno-unused-result", "-Wno-unused-value", "-L" + LIB, f"-lqwen3tts{tag}", "-Wl,-rpath,$ORIGIN"] + \
+              (["-DQ3_TIMELINE"] if timeline else []) + EXTRA
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -181,3 +181,12 @@ void ModelCfg::from_pack(const Pack& p) {
 }
 
 }  // namespace q3
+
+// ---- device selection (include/qwen3tts_engine.h): one process per GPU ----
+extern "C" int q3_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+// Select the HIP device used by every handle created afterwards on this thread.
+extern "C" int q3_set_device(int dev) { return hipSetDevice(dev) == hipSuccess ? 0 : -1; }

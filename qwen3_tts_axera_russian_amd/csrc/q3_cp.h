@@ -16,6 +16,8 @@ struct CpFrameIO {
     float temperature = 0.f;
     int top_k = 50;
     unsigned long long seed = 0;
+    const unsigned long long* seed_ptr = nullptr;  // device scalar overriding `seed` (engine: advanced per request)
+    const int* forced = nullptr;                   // teacher forcing (tests): see TalkerSampleArgs
 };
 
 // w.h / w.ssq hold the talker hidden of each row (position 0 input).  Runs positions 0..n_groups,

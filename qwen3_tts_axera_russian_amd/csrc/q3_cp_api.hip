@@ -19,7 +19,7 @@ int cp_frame(hipStream_t s, const Model& m, Work& w, KVCache& kv, int R, const C
     if (run_stack(s, m, m.cp, w, kv, R, rm, 256, row0)) return -1;
     // position 1: TALKER codec embedding of code_0 (:97-98,123-124)
     if (launch_gather_embed(s, m.talker_emb, c.talker_vocab, H, io.codes, 0, io.n_frames, io.frame_cap, 0, w.h, w.ssq, R,
-                            row0, R_total))
+                            row0, R_total, io.forced))
         return -1;
     for (int g = 0; g < G; g++) {
         rm.pos_base = g + 1;
@@ -54,6 +54,8 @@ int cp_frame(hipStream_t s, const Model& m, Work& w, KVCache& kv, int R, const C
         x.temperature = io.temperature;
         x.top_k = io.top_k;
         x.seed = io.seed;
+        x.seed_ptr = io.seed_ptr;
+        x.forced = io.forced;
         if (g + 1 < G) {
             x.next_table = m.cp_emb[g];  // group g+1 embeds token g with CP table g (:134)
             x.h_out = w.h;

@@ -26,6 +26,10 @@ struct Engine {
     int *d_past = nullptr, *d_npast = nullptr, *d_ntext = nullptr, *d_done = nullptr, *d_nframes = nullptr;
     int *d_pos0 = nullptr, *d_posdec = nullptr, *d_lastrow = nullptr;
     int* d_codes = nullptr;  // [max_frames][B][16]
+    int* d_forced = nullptr; // [max_frames][B][16] teacher-forced ids (q3e_set_forced_codes), allocated on first use
+    bool forced_on = false;
+    unsigned long long* d_seed = nullptr;  // draw-stream seed of the current request (device scalar: graph-safe)
+    unsigned long long n_requests = 0;
     float* d_pad = nullptr;
     // run state
     int B = 0, ignore_eos = 0, cap_frames = 0, frames_run = 0;
@@ -100,6 +104,8 @@ int frame_chain(Engine* e, hipStream_t st, int row0, int R) {
     sa.top_k = e->t_top_k;
     sa.top_p = e->t_top_p;
     sa.seed = e->seed;
+    sa.seed_ptr = e->d_seed;
+    sa.forced = e->forced_on ? e->d_forced : nullptr;
     if (launch_talker_sample(st, sa)) return -1;
     CpFrameIO io;
     io.codes = e->d_codes;
@@ -111,6 +117,8 @@ int frame_chain(Engine* e, hipStream_t st, int row0, int R) {
     io.temperature = e->c_temp;
     io.top_k = e->c_top_k;
     io.seed = e->seed ^ 0x5851F42D4C957F2Dull;
+    io.seed_ptr = e->d_seed;   // (the group index separates the talker's and the code predictor's draws)
+    io.forced = e->forced_on ? e->d_forced : nullptr;
     if (cp_frame(st, m, e->wc, e->kv_c, R, io, row0, e->B)) return -1;
     RowMap rm;
     rm.slot = e->d_iota;
@@ -170,7 +178,7 @@ void q3e_free(void* ee) {
     work_free(e->wt);
     work_free(e->wc);
     void* ps[] = {e->d_slot, e->d_pos,  e->d_iota,   e->d_past,    e->d_npast, e->d_ntext, e->d_done,
-                  e->d_nframes, e->d_pos0, e->d_posdec, e->d_lastrow, e->d_codes, e->d_pad};
+                  e->d_nframes, e->d_pos0, e->d_posdec, e->d_lastrow, e->d_codes, e->d_pad, e->d_forced, e->d_seed};
     for (void* p : ps)
         if (p) hipFree(p);
     if (e->h_done) hipHostFree(e->h_done);
@@ -231,6 +239,8 @@ void* q3e_create(const char* weights, int max_batch, int n_ctx, int max_frames) 
     ok = ok && ialloc(&e->d_lastrow, max_batch);
     ok = ok && ialloc(&e->d_codes, (size_t)max_frames * max_batch * 16);
     ok = ok && hipMalloc((void**)&e->d_pad, sizeof(float) * c.hidden) == hipSuccess;
+    ok = ok && hipMalloc((void**)&e->d_seed, sizeof(unsigned long long)) == hipSuccess;
+    ok = ok && hipMemset(e->d_seed, 0, sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&e->h_done, sizeof(int) * max_batch, 0) == hipSuccess;
     if (ok) {
         std::vector<int> iota(max_batch);
@@ -256,7 +266,26 @@ int q3e_set_sampling(void* ee, float talker_temperature, int talker_top_k, float
     e->c_temp = cp_temperature;
     e->c_top_k = cp_top_k;
     e->seed = seed;
+    e->n_requests = 0;
     for (auto& g : e->graph) g.reset();  // the captured kernels carry the old parameters
+    return 0;
+}
+
+int q3e_set_forced_codes(void* ee, const int32_t* forced, int n_frames) {
+    Engine* e = (Engine*)ee;
+    if (!e) return -1;
+    const bool on = forced != nullptr && n_frames > 0;
+    if (on) {
+        if (e->B <= 0 || n_frames > e->max_frames) return -1;
+        const size_t total = (size_t)e->max_frames * e->max_batch * 16;
+        if (!e->d_forced) Q3_HIP(hipMalloc((void**)&e->d_forced, sizeof(int) * total), -1);
+        Q3_HIP(hipMemset(e->d_forced, 0xff, sizeof(int) * total), -1);   // -1 = free-running
+        Q3_HIP(hipMemcpy(e->d_forced, forced, sizeof(int) * 16 * (size_t)e->B * n_frames, hipMemcpyHostToDevice), -1);
+    }
+    if (on != e->forced_on) {
+        e->forced_on = on;
+        for (auto& g : e->graph) g.reset();  // the captured kernels carry the old pointer
+    }
     return 0;
 }
 
@@ -302,6 +331,17 @@ int q3e_start(void* ee, int B, const float* prefix, const int32_t* n_rows, const
     Q3_HIP(hipMemsetAsync(e->d_nframes, 0, sizeof(int) * B, e->s), -1);
     Q3_HIP(hipMemsetAsync(e->d_past, 0, sizeof(int) * 32 * B, e->s), -1);
     Q3_HIP(hipMemsetAsync(e->d_codes, 0xff, sizeof(int) * 16 * (size_t)B * e->max_frames, e->s), -1);
+    {   // a fresh draw stream per request (the reference's generators advance from their seed across requests)
+        unsigned long long z = e->seed + 0x9E3779B97F4A7C15ull * e->n_requests++;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        const unsigned long long req_seed = e->n_requests == 1 ? e->seed : (z ^ (z >> 31));
+        Q3_HIP(hipMemcpy(e->d_seed, &req_seed, sizeof(req_seed), hipMemcpyHostToDevice), -1);
+    }
+    if (e->forced_on) {   // forcing belongs to the batch it was set for
+        e->forced_on = false;
+        for (auto& g : e->graph) g.reset();
+    }
     Q3_HIP(hipMemcpyAsync(e->d_ntext, n_text, sizeof(int) * B, hipMemcpyHostToDevice, e->s), -1);
     Q3_HIP(hipMemcpyAsync(e->d_pos0, pos0.data(), sizeof(int) * B, hipMemcpyHostToDevice, e->s), -1);
     Q3_HIP(hipMemcpyAsync(e->d_posdec, pos0.data(), sizeof(int) * B, hipMemcpyHostToDevice, e->s), -1);
@@ -379,6 +419,11 @@ int q3e_start(void* ee, int B, const float* prefix, const int32_t* n_rows, const
 int q3e_run(void* ee, int n_frames) {
     Engine* e = (Engine*)ee;
     if (!e || e->B <= 0 || n_frames <= 0) return -1;
+    // never step past the frames the batch was started for (nor past the codes array): a further step would
+    // have no frame to record into
+    const int room = (e->cap_frames < e->max_frames ? e->cap_frames : e->max_frames) - e->frames_run;
+    if (room <= 0) return 0;
+    if (n_frames > room) n_frames = room;
     int done_frames = 0;
     const int nc = n_chains_eff(e);
     Q3_HIP(hipEventRecord(e->ev0, e->s), -1);

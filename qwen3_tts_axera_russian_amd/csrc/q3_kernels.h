@@ -95,7 +95,7 @@ int launch_final_norm(hipStream_t s, const FinalNormArgs& a);
 // TalkerSampleArgs (frame = n_frames[r]-1, clamped to [0, frame_cap)).
 int launch_gather_embed(hipStream_t s, const float* table, int V, int H, const int* tok, int tok_stride,
                         const int* n_frames, int frame_cap, int col, float* h, float* ssq, int R, int row0 = 0,
-                        int R_total = 0);
+                        int R_total = 0, const int* forced = nullptr);
 
 // Talker sampling (llamacpp_talker_server.py:163-206, greedy form).
 struct TalkerSampleArgs {
@@ -119,8 +119,12 @@ struct TalkerSampleArgs {
     float rep_penalty = 1.2f;
     // temperature <= 1e-6: arg-max (the reference's limit); else top-k / temperature / top-p on the device
     float temperature = 0.f, top_p = 0.95f;
-    int top_k = 50;
+    int top_k = 50;              // <= 0 or >= V: every entry (the reference skips its argpartition then)
     unsigned long long seed = 0;
+    const unsigned long long* seed_ptr = nullptr;  // device scalar overriding `seed` (advanced per request, graph-safe)
+    // teacher forcing (tests): same layout as `codes`; entries >= 0 replace the decision that is FED BACK
+    // (ring of past ids, CP input, feedback sum) while `codes` still records what the device decided
+    const int* forced = nullptr;
 };
 int launch_talker_sample(hipStream_t s, const TalkerSampleArgs& a);
 
@@ -144,8 +148,10 @@ struct CpArgmaxArgs {
     const float* pad_embed = nullptr;
     int n_groups = 15;
     float temperature = 0.f;   // <= 1e-6: arg-max
-    int top_k = 50;
+    int top_k = 50;            // <= 0 or >= V: every entry
     unsigned long long seed = 0;
+    const unsigned long long* seed_ptr = nullptr;  // device scalar overriding `seed`
+    const int* forced = nullptr;                   // teacher forcing (tests), see TalkerSampleArgs
 };
 int launch_cp_argmax(hipStream_t s, const CpArgmaxArgs& a);
 

@@ -538,7 +538,8 @@ __device__ __forceinline__ void store_row_ssq(float* h, float* ssq, int r, int H
 
 __global__ void gather_embed_kernel(const float* __restrict__ table, int V, int H, const int* __restrict__ tok,
                                     int tok_stride, const int* __restrict__ n_frames, int frame_cap, int col,
-                                    float* __restrict__ h, float* __restrict__ ssq, int row0, int R_total) {
+                                    float* __restrict__ h, float* __restrict__ ssq, int row0, int R_total,
+                                    const int* __restrict__ forced) {
     const int r = row0 + blockIdx.x;
     int t;
     if (n_frames) {
@@ -546,6 +547,10 @@ __global__ void gather_embed_kernel(const float* __restrict__ table, int V, int 
         if (f < 0) f = 0;
         if (f >= frame_cap) f = frame_cap - 1;
         t = tok[((size_t)f * R_total + r) * 16 + col];
+        if (forced) {   // teacher forcing (tests): continue with the forced id where one is given
+            const int fz = forced[((size_t)f * R_total + r) * 16 + col];
+            if (fz >= 0 && t >= 0) t = fz;
+        }
     } else {
         t = tok[(size_t)r * tok_stride];
     }
@@ -558,10 +563,10 @@ __global__ void gather_embed_kernel(const float* __restrict__ table, int V, int 
 }
 int launch_gather_embed(hipStream_t s, const float* table, int V, int H, const int* tok, int tok_stride,
                         const int* n_frames, int frame_cap, int col, float* h, float* ssq, int R, int row0,
-                        int R_total) {
+                        int R_total, const int* forced) {
     if (R <= 0) return 0;
     hipLaunchKernelGGL(gather_embed_kernel, dim3(R), dim3(256), 0, s, table, V, H, tok, tok_stride, n_frames,
-                       frame_cap, col, h, ssq, row0, R_total > 0 ? R_total : R);
+                       frame_cap, col, h, ssq, row0, R_total > 0 ? R_total : R, forced);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
 }
@@ -984,63 +989,159 @@ __device__ __forceinline__ float uniform01(unsigned long long seed, unsigned row
     return (float)(z >> 40) * (1.0f / 16777216.0f);   // 24 bits -> [0, 1)
 }
 
-// lg: n processed logits in LDS (destroyed).  Picks the top_k largest (ties: lowest index first), applies
-// softmax((l - max) / max(T, 1e-6)) like the reference samplers, optionally keeps the smallest prefix of
-// the descending order whose mass reaches top_p (llamacpp_talker_server.py:199-205), and draws with u.
-// All threads of the block must call it; every thread returns the chosen index.
+// NaN logits: numpy's argmax (the reference's greedy limit) lets the first NaN win; the device does the same by
+// ordering a NaN as +inf.  A row whose best key is not finite (NaN, +inf, or nothing but -inf) has no softmax:
+// the sampler then returns that best index instead of drawing (the reference would raise inside np.random.choice
+// and answer -2; a device kernel cannot raise, and must never index with an invalid winner).
+__device__ __forceinline__ float nan_as_inf(float l) { return l != l ? INFINITY : l; }
+
+constexpr int SAMPLE_SEL_CAP = 64;      // top_k up to this: k selection rounds; beyond (or "all"): a full LDS sort
+constexpr int SAMPLE_SORT_CAP = 4096;   // largest vocabulary the full sort handles (talker 3072, code predictor 2048)
+// top_k as the reference means it: <= 0 or >= n keeps every entry (np.argpartition is skipped there)
+__host__ __device__ __forceinline__ int effective_top_k(int top_k, int n) { return (top_k <= 0 || top_k > n) ? n : top_k; }
+__host__ __device__ __forceinline__ int sample_sort_len(int n) {
+    int p = 64;
+    while (p < n) p <<= 1;
+    return p;
+}
+// dynamic LDS bytes the samplers need for a vocabulary of n at this top_k (0 when greedy)
+static size_t sample_lds_bytes(int n, int top_k, float temperature) {
+    if (!(temperature > 1e-6f)) return 0;
+    return effective_top_k(top_k, n) <= SAMPLE_SEL_CAP ? (size_t)n * 4 : (size_t)sample_sort_len(n) * 8;
+}
+
+// lg: n processed logits in LDS (destroyed; capacity n floats, or sample_sort_len(n) floats followed by as many
+// ints when top_k needs the full sort).  Keeps the top_k largest (ties: lowest index first), applies
+// softmax((l - max) / max(T, 1e-6)) like the reference samplers, optionally keeps the smallest prefix of the
+// descending order whose mass reaches top_p (llamacpp_talker_server.py:199-205), and draws with u.
+// All threads of the block must call it; every thread returns the chosen index (always in [0, n)).
 __device__ int block_sample_topk(float* lg, int n, int top_k, float temperature, float top_p, float u, float* sv,
                                  int* si, float* selv, int* seli) {
-    if (top_k > 64) top_k = 64;
-    if (top_k > n) top_k = n;
-    for (int k = 0; k < top_k; k++) {
-        float best = -INFINITY;
-        int bidx = 0x7fffffff;
-        for (int v = threadIdx.x; v < n; v += blockDim.x) {
-            const float l = lg[v];
-            if (l > best) {
-                best = l;
-                bidx = v;
-            }
-        }
-        block_argmax(best, bidx, sv, si);
-        if (threadIdx.x == 0) {
-            selv[k] = best;
-            seli[k] = bidx;
-            lg[bidx] = -INFINITY;
-        }
-        __syncthreads();
-    }
-    // the selection is in descending order: selv[0] is the maximum
     __shared__ int chosen;
-    if (threadIdx.x == 0) {
-        const float inv_t = 1.0f / fmaxf(temperature, 1e-6f);
-        float sum = 0.f;
+    top_k = effective_top_k(top_k, n);
+    const float inv_t = 1.0f / fmaxf(temperature, 1e-6f);
+    if (top_k <= SAMPLE_SEL_CAP) {
+        int found = 0;
         for (int k = 0; k < top_k; k++) {
-            selv[k] = expf((selv[k] - selv[0]) * inv_t);
-            sum += selv[k];
-        }
-        int keep = top_k;
-        if (top_p > 0.f && top_p < 1.f) {
-            float c = 0.f;
-            keep = top_k;
-            for (int k = 0; k < top_k; k++) {
-                c += selv[k] / sum;
-                if (c >= top_p) {   // np.searchsorted(cumsum, top_p) + 1 entries
-                    keep = k + 1;
-                    break;
+            float best = -INFINITY;
+            int bidx = 0x7fffffff;
+            for (int v = threadIdx.x; v < n; v += blockDim.x) {
+                const float l = lg[v];
+                if (l > best) {
+                    best = l;
+                    bidx = v;
                 }
             }
-            sum = 0.f;
-            for (int k = 0; k < keep; k++) sum += selv[k];
+            block_argmax(best, bidx, sv, si);
+            if (bidx >= n) break;            // nothing above -inf is left (block-uniform)
+            if (threadIdx.x == 0) {
+                selv[k] = best;
+                seli[k] = bidx;
+                lg[bidx] = -INFINITY;
+            }
+            found = k + 1;
+            __syncthreads();
         }
-        float c = 0.f;
-        int pick = seli[keep - 1];
-        const float target = u * sum;
-        for (int k = 0; k < keep; k++) {
-            c += selv[k];
-            if (target < c) {
-                pick = seli[k];
-                break;
+        if (threadIdx.x == 0) {
+            int pick = 0;
+            if (found > 0 && !(selv[0] < INFINITY)) pick = seli[0];       // NaN / +inf on top: no softmax exists
+            else if (found > 0) {
+                // the selection is in descending order: selv[0] is the maximum
+                float sum = 0.f;
+                for (int k = 0; k < found; k++) {
+                    selv[k] = expf((selv[k] - selv[0]) * inv_t);
+                    sum += selv[k];
+                }
+                int keep = found;
+                if (top_p > 0.f && top_p < 1.f) {
+                    float c = 0.f;
+                    for (int k = 0; k < found; k++) {
+                        c += selv[k] / sum;
+                        if (c >= top_p) {   // np.searchsorted(cumsum, top_p) + 1 entries
+                            keep = k + 1;
+                            break;
+                        }
+                    }
+                    sum = 0.f;
+                    for (int k = 0; k < keep; k++) sum += selv[k];
+                }
+                float c = 0.f;
+                pick = seli[keep - 1];
+                const float target = u * sum;
+                for (int k = 0; k < keep; k++) {
+                    c += selv[k];
+                    if (target < c) {
+                        pick = seli[k];
+                        break;
+                    }
+                }
+            }
+            chosen = pick;
+        }
+        __syncthreads();
+        return chosen;
+    }
+    // ---- top_k beyond the selection cap (or "all"): bitonic sort of (key, index), descending key, ascending index ----
+    const int n2 = sample_sort_len(n);
+    int* li = (int*)(lg + n2);
+    for (int v = threadIdx.x; v < n2; v += blockDim.x) {
+        if (v >= n) lg[v] = -INFINITY;
+        li[v] = v;
+    }
+    __syncthreads();
+    for (int k2 = 2; k2 <= n2; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const float a0 = lg[i], a1 = lg[ixj];
+                    const int i0 = li[i], i1 = li[ixj];
+                    const bool before = a0 > a1 || (a0 == a1 && i0 < i1);   // element i belongs ahead of element ixj
+                    const bool desc = (i & k2) == 0;
+                    if (desc ? !before : before) {
+                        lg[i] = a1;
+                        lg[ixj] = a0;
+                        li[i] = i1;
+                        li[ixj] = i0;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    if (threadIdx.x == 0) {
+        int pick = li[0] < n ? li[0] : 0;
+        const float top = lg[0];
+        if (top < INFINITY && top > -INFINITY) {
+            float sum = 0.f;
+            int found = 0;
+            for (int k = 0; k < top_k; k++) {
+                if (!(lg[k] > -INFINITY)) break;
+                lg[k] = expf((lg[k] - top) * inv_t);
+                sum += lg[k];
+                found = k + 1;
+            }
+            int keep = found;
+            if (top_p > 0.f && top_p < 1.f) {
+                float c = 0.f;
+                for (int k = 0; k < found; k++) {
+                    c += lg[k] / sum;
+                    if (c >= top_p) {
+                        keep = k + 1;
+                        break;
+                    }
+                }
+                sum = 0.f;
+                for (int k = 0; k < keep; k++) sum += lg[k];
+            }
+            float c = 0.f;
+            pick = li[keep - 1];
+            const float target = u * sum;
+            for (int k = 0; k < keep; k++) {
+                c += lg[k];
+                if (target < c) {
+                    pick = li[k];
+                    break;
+                }
             }
         }
         chosen = pick;
@@ -1088,7 +1189,7 @@ __global__ void talker_sample_kernel(TalkerSampleArgs a) {
     __shared__ int seli[64];
     const bool stochastic = a.temperature > 1e-6f;
     for (int v = threadIdx.x; v < a.V; v += blockDim.x) {
-        float l = a.logits[(size_t)r * a.V + v];
+        float l = nan_as_inf(a.logits[(size_t)r * a.V + v]);
         if (v >= a.audio_vocab && v != a.eos) l = -1e10f;
         if (v == a.eos) {
             if (a.ignore_eos) l = -1e10f;
@@ -1105,25 +1206,32 @@ __global__ void talker_sample_kernel(TalkerSampleArgs a) {
     }
     if (stochastic) {
         __syncthreads();
-        const float u = uniform01(a.seed, (unsigned)r, (unsigned)a.n_frames[r], 0u);
+        const float u = uniform01(a.seed_ptr ? *a.seed_ptr : a.seed, (unsigned)r, (unsigned)a.n_frames[r], 0u);
         bidx = block_sample_topk(slg, a.V, a.top_k, a.temperature, a.top_p, u, sv, si, selv, seli);
     } else {
         block_argmax(best, bidx, sv, si);
+        if (bidx >= a.V) bidx = a.eos;   // unreachable (the mask leaves finite entries); never index with an invalid winner
     }
     if (threadIdx.x == 0) {
         int code = bidx;
         if (force_eos && !a.ignore_eos) code = a.eos;
         bool fin = was_done || code == a.eos || code >= a.audio_vocab || (a.max_frames > 0 && np >= a.max_frames);
-        int f = a.n_frames[r];
+        const int f = a.n_frames[r];
         a.n_frames[r] = f + 1;
-        if (f >= a.frame_cap) f = a.frame_cap - 1;
-        int* fc = a.codes + ((size_t)f * RT + r) * 16;
-        if (fin) {
+        const bool keep = f < a.frame_cap;     // a frame beyond the codes array is not recorded (q3e_run never asks for one)
+        int* fc = a.codes + ((size_t)(keep ? f : 0) * RT + r) * 16;
+        // teacher forcing (tests): the decision is recorded, the forced id is what the stream continues with
+        int used = code;
+        if (a.forced && keep && !fin) {
+            const int fz = a.forced[((size_t)f * RT + r) * 16];
+            if (fz >= 0) used = fz;
+        }
+        if (fin || !keep) {
             a.done[r] = 1;
-            fc[0] = -1;
+            if (keep) fc[0] = -1;
         } else {
             fc[0] = code;
-            a.past[r * 32 + (np & 31)] = code;
+            a.past[r * 32 + (np & 31)] = used;
             a.n_past[r] = np + 1;
             a.pos[r] = a.pos0[r] + np;
         }
@@ -1131,7 +1239,12 @@ __global__ void talker_sample_kernel(TalkerSampleArgs a) {
 }
 int launch_talker_sample(hipStream_t s, const TalkerSampleArgs& a) {
     if (a.R <= 0) return 0;
-    const size_t lds = a.temperature > 1e-6f ? (size_t)a.V * sizeof(float) : 0;
+    if (a.temperature > 1e-6f && effective_top_k(a.top_k, a.V) > SAMPLE_SEL_CAP && a.V > SAMPLE_SORT_CAP) {
+        Q3_LOG("talker_sample: top_k=%d over a vocabulary of %d is beyond the device sampler (sort cap %d)", a.top_k, a.V,
+               SAMPLE_SORT_CAP);
+        return -1;
+    }
+    const size_t lds = sample_lds_bytes(a.V, a.top_k, a.temperature);
     TalkerSampleArgs a2 = a;
     a2.tl_node = tl_next_node();
     hipLaunchKernelGGL(talker_sample_kernel, dim3(a.R), dim3(256), lds, s, a2);
@@ -1147,14 +1260,17 @@ int launch_talker_sample(hipStream_t s, const TalkerSampleArgs& a) {
 __device__ __forceinline__ void feedback_row(const int* codes, int r, const float* talker_emb, int talker_vocab,
                                              const float* const* cp_tables, int cp_vocab, int n_groups,
                                              const float* pad, float* h_out, float* ssq_out, int H,
-                                             int ov_g = -1, int ov_tok = 0) {
+                                             int ov_g = -1, int ov_tok = 0, const int* fz = nullptr) {
     // tts_client.py:199-208: copy codec_embedding[code_0], += cp table g row, += tts_pad, in this order
-    const int c0 = codes[0];
+    // (fz: teacher-forced ids of this frame, tests only -- entries >= 0 replace the recorded decisions)
+    int c0 = codes[0];
+    if (fz && fz[0] >= 0 && c0 >= 0) c0 = fz[0];
     for (int k4 = threadIdx.x; k4 < H / 4; k4 += blockDim.x) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c0 >= 0 && c0 < talker_vocab) v = *(const float4*)(talker_emb + (size_t)c0 * H + k4 * 4);
         for (int g = 0; g < n_groups; g++) {
-            const int t = g == ov_g ? ov_tok : codes[1 + g];
+            int t = g == ov_g ? ov_tok : codes[1 + g];
+            if (fz && g != ov_g && fz[1 + g] >= 0) t = fz[1 + g];
             if (t >= 0 && t < cp_vocab) {
                 const float4 e = *(const float4*)(cp_tables[g] + (size_t)t * H + k4 * 4);
                 v.x += e.x;
@@ -1192,7 +1308,8 @@ __global__ void __launch_bounds__(256) cp_argmax_kernel(CpArgmaxArgs a) {
     const int nf_r = a.n_frames[r];   // independent of the arg-max: requested with the logits, not after them
     Q3_PH(0);
     {
-        const float e[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+        const float e[8] = {nan_as_inf(l0.x), nan_as_inf(l0.y), nan_as_inf(l0.z), nan_as_inf(l0.w),
+                            nan_as_inf(l1.x), nan_as_inf(l1.y), nan_as_inf(l1.z), nan_as_inf(l1.w)};
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int idx = (j < 4 ? tid : tid + 256) * 4 + (j & 3);
@@ -1204,7 +1321,7 @@ __global__ void __launch_bounds__(256) cp_argmax_kernel(CpArgmaxArgs a) {
     }
     for (int v4 = tid + 512; v4 < n4; v4 += 256) {   // vocabularies beyond 2048
         const float4 l = lg[v4];
-        const float e[4] = {l.x, l.y, l.z, l.w};
+        const float e[4] = {nan_as_inf(l.x), nan_as_inf(l.y), nan_as_inf(l.z), nan_as_inf(l.w)};
 #pragma unroll
         for (int j = 0; j < 4; j++)
             if (e[j] > best) {
@@ -1242,20 +1359,24 @@ __global__ void __launch_bounds__(256) cp_argmax_kernel(CpArgmaxArgs a) {
         __shared__ float sv2[16];
         __shared__ int si2[16];
         __syncthreads();
-        for (int v = tid; v < a.V; v += 256) slg[v] = a.logits[(size_t)r * a.V + v];
+        for (int v = tid; v < a.V; v += 256) slg[v] = nan_as_inf(a.logits[(size_t)r * a.V + v]);
         __syncthreads();
-        const float u = uniform01(a.seed, (unsigned)r, (unsigned)nf_r, 1u + (unsigned)a.group);
+        const float u = uniform01(a.seed_ptr ? *a.seed_ptr : a.seed, (unsigned)r, (unsigned)nf_r, 1u + (unsigned)a.group);
         bidx = block_sample_topk(slg, a.V, a.top_k, a.temperature, 0.f, u, sv2, si2, selv, seli);
     }
+    if (bidx < 0 || bidx >= a.V) bidx = 0;   // every logit -inf: numpy's argmax answers 0; never gather with an invalid winner
     int f = nf_r - 1;
     if (f < 0) f = 0;
-    if (f >= a.frame_cap) f = a.frame_cap - 1;
+    const bool keep = f < a.frame_cap;        // a frame beyond the codes array is not recorded
+    if (!keep) f = a.frame_cap - 1;
     int* fc = a.codes + ((size_t)f * RT + r) * 16;
-    if (tid == 0) fc[1 + a.group] = bidx;
+    if (tid == 0 && keep) fc[1 + a.group] = bidx;
+    const int* fz = (a.forced && keep) ? a.forced + ((size_t)f * RT + r) * 16 : nullptr;
+    if (fz && fz[1 + a.group] >= 0) bidx = fz[1 + a.group];   // teacher forcing (tests): continue with the forced id
     Q3_PH(2);
     if (a.talker_emb) {
         feedback_row(fc, r, a.talker_emb, a.talker_vocab, a.cp_tables, a.V, a.n_groups, a.pad_embed,
-                     a.h_out, a.ssq_out, a.H, a.group, bidx);
+                     a.h_out, a.ssq_out, a.H, a.group, bidx, fz);
     } else if (a.next_table) {
         for (int k4 = tid; k4 < a.H / 4; k4 += 256) {
             const float4 v = *(const float4*)(a.next_table + (size_t)bidx * a.H + k4 * 4);
@@ -1265,7 +1386,12 @@ __global__ void __launch_bounds__(256) cp_argmax_kernel(CpArgmaxArgs a) {
 }
 int launch_cp_argmax(hipStream_t s, const CpArgmaxArgs& a) {
     if (a.R <= 0) return 0;
-    const size_t lds = a.temperature > 1e-6f ? (size_t)a.V * sizeof(float) : 0;
+    if (a.temperature > 1e-6f && effective_top_k(a.top_k, a.V) > SAMPLE_SEL_CAP && a.V > SAMPLE_SORT_CAP) {
+        Q3_LOG("cp_argmax: top_k=%d over a vocabulary of %d is beyond the device sampler (sort cap %d)", a.top_k, a.V,
+               SAMPLE_SORT_CAP);
+        return -1;
+    }
+    const size_t lds = sample_lds_bytes(a.V, a.top_k, a.temperature);
     CpArgmaxArgs a2 = a;
     a2.tl_node = tl_next_node();
     hipLaunchKernelGGL(cp_argmax_kernel, dim3(a.R), dim3(256), lds, s, a2);

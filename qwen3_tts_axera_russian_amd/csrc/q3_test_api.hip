@@ -1,4 +1,6 @@
-// q3_test_api.hip -- kernel-level entry points used only by tests/ (host arrays in, host arrays out).
+// q3_test_api.hip -- kernel-level entry points used only by tests/ and bench.py (host arrays in, host arrays
+// out).  Built into lib/libqwen3tts_test.so, which links against the product library; NOT part of
+// libqwen3tts.so / llama_wrapper.so.
 #include "q3_model.h"
 #include <chrono>
 
@@ -23,12 +25,6 @@ struct DBuf {
 }  // namespace
 
 extern "C" {
-
-int q3t_device_count(void) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
-}
 
 int q3t_set_linear_tuning(int K, int mt16, int kbw) { return set_linear_tuning(K, mt16, kbw); }
 int q3t_set_linear_split_rows(int on) { return set_linear_split_rows(on); }
@@ -199,9 +195,6 @@ extern "C" int q3t_talker_sample(const float* logits, int V, const int* past, in
     return code;
 }
 
-// Select the HIP device used by every handle created afterwards on this thread (one process per GPU).
-extern "C" int q3_set_device(int dev) { return hipSetDevice(dev) == hipSuccess ? 0 : -1; }
-
 // ---- launch-boundary microbenchmark: a dependent chain of n small kernels, captured as a graph ----
 namespace {
 __global__ void chain_empty_kernel(float* buf) { (void)buf; }
@@ -266,214 +259,6 @@ extern "C" float q3t_bench_chain(int kind, int blocks, int threads, int n_kernel
     hipEventDestroy(e1);
     hipStreamDestroy(s);
     return ms * 1000.f / ((float)iters * n_kernels);
-}
-
-// Do graphs replayed on different streams overlap on this runtime?  n_streams graphs, each an
-// n_kernels-long dependent chain; returns the wall microseconds for one round of all graphs.
-extern "C" float q3t_bench_multistream(int n_streams, int blocks, int threads, int n_kernels, int iters, int use_graph) {
-    if (n_streams < 1 || n_streams > 8) return -1.f;
-    hipStream_t st[8];
-    hipGraph_t g[8] = {nullptr};
-    hipGraphExec_t ge[8] = {nullptr};
-    DBuf a[8], b[8];
-    const int n = blocks * threads;
-    for (int s = 0; s < n_streams; s++) {
-        if (hipStreamCreateWithFlags(&st[s], hipStreamNonBlocking) != hipSuccess) return -1.f;
-        if (!a[s].alloc((size_t)n * 4) || !b[s].alloc((size_t)n * 4)) return -1.f;
-        hipMemset(a[s].p, 0, (size_t)n * 4);
-        hipMemset(b[s].p, 0, (size_t)n * 4);
-    }
-    auto chain = [&](int s) {
-        for (int k = 0; k < n_kernels; k++) {
-            float* in = (float*)((k & 1) ? b[s].p : a[s].p);
-            float* out = (float*)((k & 1) ? a[s].p : b[s].p);
-            hipLaunchKernelGGL(chain_dep_kernel, dim3(blocks), dim3(threads), 0, st[s], in, out, n, 2);
-        }
-    };
-    for (int s = 0; s < n_streams; s++) {
-        chain(s);
-        hipStreamSynchronize(st[s]);
-        if (use_graph) {
-            hipStreamBeginCapture(st[s], hipStreamCaptureModeRelaxed);
-            chain(s);
-            if (hipStreamEndCapture(st[s], &g[s]) != hipSuccess) return -1.f;
-            if (hipGraphInstantiate(&ge[s], g[s], nullptr, nullptr, 0) != hipSuccess) return -1.f;
-        }
-    }
-    hipDeviceSynchronize();
-    auto t0 = std::chrono::steady_clock::now();
-    for (int it = 0; it < iters; it++)
-        for (int s = 0; s < n_streams; s++) {
-            if (use_graph) hipGraphLaunch(ge[s], st[s]);
-            else chain(s);
-        }
-    hipDeviceSynchronize();
-    auto t1 = std::chrono::steady_clock::now();
-    for (int s = 0; s < n_streams; s++) {
-        if (ge[s]) hipGraphExecDestroy(ge[s]);
-        if (g[s]) hipGraphDestroy(g[s]);
-        hipStreamDestroy(st[s]);
-    }
-    return (float)(std::chrono::duration<double, std::micro>(t1 - t0).count() / iters);
-}
-
-// ---- does a kernel's resource footprint change the per-node dispatch cost? ----
-namespace {
-__global__ void __launch_bounds__(256) chain_fat_vgpr_kernel(float* buf) {
-    // touches a high VGPR so the descriptor allocates ~256 registers per lane
-    asm volatile("v_mov_b32 v250, 0" ::: "v250");
-    (void)buf;
-}
-struct BigArgs {
-    float* p[20];
-    int v[16];
-};
-__global__ void chain_bigargs_kernel(BigArgs a) { (void)a; }
-}  // namespace
-
-// variant 0: empty, 1: 256-VGPR descriptor, 2: 80 KB dynamic LDS, 3: 224-byte kernarg
-extern "C" float q3t_bench_chain_footprint(int variant, int blocks, int threads, int n_kernels, int iters) {
-    hipStream_t s = nullptr;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return -1.f;
-    DBuf a;
-    a.alloc(4096);
-    if (variant == 2)
-        hipFuncSetAttribute((const void*)chain_empty_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    BigArgs ba;
-    memset(&ba, 0, sizeof(ba));
-    auto chain = [&]() {
-        for (int k = 0; k < n_kernels; k++) {
-            if (variant == 1) hipLaunchKernelGGL(chain_fat_vgpr_kernel, dim3(blocks), dim3(threads), 0, s, (float*)a.p);
-            else if (variant == 2) hipLaunchKernelGGL(chain_empty_kernel, dim3(blocks), dim3(threads), 80 * 1024, s, (float*)a.p);
-            else if (variant == 3) hipLaunchKernelGGL(chain_bigargs_kernel, dim3(blocks), dim3(threads), 0, s, ba);
-            else hipLaunchKernelGGL(chain_empty_kernel, dim3(blocks), dim3(threads), 0, s, (float*)a.p);
-        }
-    };
-    hipGraph_t g = nullptr;
-    hipGraphExec_t ge = nullptr;
-    chain();
-    hipStreamSynchronize(s);
-    hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
-    chain();
-    if (hipStreamEndCapture(s, &g) != hipSuccess) return -1.f;
-    if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) return -1.f;
-    hipGraphLaunch(ge, s);
-    hipStreamSynchronize(s);
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    hipEventRecord(e0, s);
-    for (int it = 0; it < iters; it++) hipGraphLaunch(ge, s);
-    hipEventRecord(e1, s);
-    hipStreamSynchronize(s);
-    float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipGraphExecDestroy(ge);
-    hipGraphDestroy(g);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    hipStreamDestroy(s);
-    return ms * 1000.f / ((float)iters * n_kernels);
-}
-
-// ---- feasibility probe: dependent kernels alternated over n_streams queues, ordered by in-kernel
-// arrival counters instead of the queue barrier, so kernel k+1 is resident (and has its read-only
-// operands in flight) while kernel k still runs.  Returns microseconds per node; *ok_out = 1 when no
-// spin timed out and every element went through every node exactly once.
-namespace {
-typedef unsigned __attribute__((address_space(1))) gu32_t;
-__global__ void handoff_kernel(unsigned* seq, int node, int n_nodes, int G, const float4* __restrict__ wts,
-                               int w_per_thread, const float* in, float* out, int n, unsigned* tmo) {
-    const int tid = threadIdx.x;
-    // "weights": independent of the predecessor, requested first
-    float4 wacc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4* wp = wts + ((size_t)blockIdx.x * blockDim.x + tid) * w_per_thread;
-    for (int i = 0; i < w_per_thread; i++) {
-        const float4 v = wp[i];
-        wacc.x += v.x; wacc.y += v.y; wacc.z += v.z; wacc.w += v.w;
-    }
-    __shared__ int ok_s;
-    if (tid == 0) {
-        const unsigned r = __hip_atomic_load(seq + node, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (unsigned)G;
-        const int pred = node == 0 ? n_nodes - 1 : node - 1;
-        const unsigned target = (node == 0 ? r : r + 1) * (unsigned)G;
-        int ok = 0;
-        for (unsigned spins = 0; spins < (1u << 15); spins++) {
-            if (__hip_atomic_load(seq + pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        if (!ok) __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok_s = ok;
-    }
-    __syncthreads();
-    for (int i = blockIdx.x * blockDim.x + tid; i < n; i += gridDim.x * blockDim.x) {
-        const float v = __hip_atomic_load(in + (i + 17) % n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(out + i, v + 1.0f + 0.f * wacc.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(seq + node, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-}  // namespace
-
-extern "C" float q3t_bench_handoff(int n_streams, int blocks, int threads, int n_kernels, int iters, int w_per_thread,
-                                   int n_elems, int* ok_out) {
-    if (ok_out) *ok_out = 0;
-    if (n_streams < 1 || n_streams > 4 || n_kernels % n_streams || n_kernels % 2) return -1.f;
-    hipStream_t st[4];
-    hipGraph_t g[4] = {nullptr};
-    hipGraphExec_t ge[4] = {nullptr};
-    DBuf seq, tmo, a, b, w;
-    const size_t wbytes = (size_t)blocks * threads * (w_per_thread > 0 ? w_per_thread : 1) * 16;
-    if (!seq.alloc((size_t)n_kernels * 4) || !tmo.alloc(16) || !a.alloc((size_t)n_elems * 4) || !b.alloc((size_t)n_elems * 4) ||
-        !w.alloc(wbytes * 4))
-        return -1.f;
-    hipMemset(seq.p, 0, (size_t)n_kernels * 4);
-    hipMemset(tmo.p, 0, 16);
-    hipMemset(a.p, 0, (size_t)n_elems * 4);
-    hipMemset(b.p, 0, (size_t)n_elems * 4);
-    hipMemset(w.p, 0, wbytes * 4);
-    for (int s = 0; s < n_streams; s++)
-        if (hipStreamCreateWithFlags(&st[s], hipStreamNonBlocking) != hipSuccess) return -1.f;
-    auto enqueue = [&]() {
-        for (int k = 0; k < n_kernels; k++) {
-            const float* in = (const float*)((k & 1) ? b.p : a.p);
-            float* out = (float*)((k & 1) ? a.p : b.p);
-            const float4* wk = (const float4*)((char*)w.p + (size_t)(k & 3) * wbytes);
-            hipLaunchKernelGGL(handoff_kernel, dim3(blocks), dim3(threads), 0, st[k % n_streams], (unsigned*)seq.p, k, n_kernels,
-                               blocks, wk, w_per_thread, in, out, n_elems, (unsigned*)tmo.p);
-        }
-    };
-    hipDeviceSynchronize();
-    for (int s = 0; s < n_streams; s++) hipStreamBeginCapture(st[s], hipStreamCaptureModeRelaxed);
-    enqueue();
-    for (int s = 0; s < n_streams; s++) {
-        if (hipStreamEndCapture(st[s], &g[s]) != hipSuccess) return -1.f;
-        if (hipGraphInstantiate(&ge[s], g[s], nullptr, nullptr, 0) != hipSuccess) return -1.f;
-    }
-    auto round = [&]() {
-        for (int s = 0; s < n_streams; s++) hipGraphLaunch(ge[s], st[s]);
-    };
-    round();   // warm-up replay
-    hipDeviceSynchronize();
-    auto t0 = std::chrono::steady_clock::now();
-    for (int it = 0; it < iters; it++) round();
-    hipDeviceSynchronize();
-    auto t1 = std::chrono::steady_clock::now();
-    unsigned h_tmo = 1;
-    hipMemcpy(&h_tmo, tmo.p, 4, hipMemcpyDeviceToHost);
-    std::vector<float> h((size_t)n_elems);
-    hipMemcpy(h.data(), a.p, (size_t)n_elems * 4, hipMemcpyDeviceToHost);   // n_kernels even: the last node wrote a
-    const float want = (float)((iters + 1) * n_kernels);
-    int good = h_tmo == 0;
-    for (int i = 0; i < n_elems; i++) good = good && h[i] == want;
-    if (ok_out) *ok_out = good;
-    for (int s = 0; s < n_streams; s++) {
-        if (ge[s]) hipGraphExecDestroy(ge[s]);
-        if (g[s]) hipGraphDestroy(g[s]);
-        hipStreamDestroy(st[s]);
-    }
-    return (float)(std::chrono::duration<double, std::micro>(t1 - t0).count() / ((double)iters * n_kernels));
 }
 
 // ---- CPU-side hook: parse weight files the way the loaders do (container, or the reference's .npz /

@@ -708,6 +708,12 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
         Q3_LOG("%s holds no vocoder program (tensor voc.program int32 [n][8])", weights);
         return nullptr;
     }
+    if (chunk_tokens > 0 && chunk_tokens <= 32) {
+        // the chunk walk steps by chunk - 16 and its output bound (n + chunk) frames needs chunk > 32; the
+        // reference's models are traced at 64 or 256 (scripts/export_vocoder_traced.py)
+        Q3_LOG("voc_load: chunk_tokens=%d is too short for the 16-frame overlap walk (need > 32)", chunk_tokens);
+        return nullptr;
+    }
     if (const char* ex = getenv("Q3_VOC_EXACT")) g_voc_split = atoi(ex) ? 0 : 1;
     Voc* v = new Voc();
     v->chunk = chunk_tokens > 0 ? chunk_tokens : 64;
@@ -1272,11 +1278,16 @@ int voc_synthesize_f32(void* vv, const int64_t* codes, int n, float* out, int32_
         return 0;
     }
     const int OVERLAP = 16, OV = OVERLAP * SPT, step = CH - OVERLAP;
+    const size_t capacity = (size_t)voc_synthesize_max_samples(v, n);   // what callers size `out` with
     size_t have = 0;
     for (int start = 0; start < n; start += step) {
         const int len = (start + CH <= n) ? CH : n - start;
         if (run_chunk(start, len)) return -1;
         const size_t cl = (size_t)len * SPT;
+        if (have + cl > capacity) {
+            Q3_LOG("voc_synthesize: chunk walk would pass the output bound (%zu + %zu > %zu)", have, cl, capacity);
+            return -1;
+        }
         if (start == 0) {
             memcpy(out, chunk.data(), sizeof(float) * cl);
             have = cl;

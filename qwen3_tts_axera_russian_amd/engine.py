@@ -44,6 +44,17 @@ class FrameEngine:
         if rc != 0:
             raise RuntimeError(f"q3e_start failed: {rc}")
 
+    def set_forced_codes(self, forced):
+        """Teacher forcing (after start()): forced[f][B][16] int32, entries < 0 free-running; None = off."""
+        if forced is None:
+            rc = self._lib.q3e_set_forced_codes(self.h, None, 0)
+        else:
+            f = np.ascontiguousarray(forced, dtype=np.int32)
+            assert f.ndim == 3 and f.shape[1] == self.B and f.shape[2] == 16
+            rc = self._lib.q3e_set_forced_codes(self.h, hiplib.iptr(f), f.shape[0])
+        if rc != 0:
+            raise RuntimeError("q3e_set_forced_codes failed")
+
     def run(self, n_frames):
         rc = self._lib.q3e_run(self.h, int(n_frames))
         if rc < 0:

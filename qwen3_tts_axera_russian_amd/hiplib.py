@@ -4,9 +4,10 @@ from __future__ import annotations
 import ctypes
 import os
 
-from . import LIB_PATH
+from . import LIB_PATH, TEST_LIB_PATH
 
 _lib = None
+_test_lib = None
 
 c_void_p, c_int, c_float, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_char_p
 f32p = ctypes.POINTER(ctypes.c_float)
@@ -63,6 +64,7 @@ def load(path: str | None = None):
     _sig(lib, "q3e_set_pad_embed", c_int, [c_void_p, f32p])
     _sig(lib, "q3e_set_chains", c_int, [c_void_p, c_int])
     _sig(lib, "q3e_set_sampling", c_int, [c_void_p, c_float, c_int, c_float, c_float, c_int, ctypes.c_uint64])
+    _sig(lib, "q3e_set_forced_codes", c_int, [c_void_p, i32p, c_int])
     _sig(lib, "q3e_start", c_int, [c_void_p, c_int, f32p, i32p, i32p, c_int, c_int])
     _sig(lib, "q3e_run", c_int, [c_void_p, c_int])
     _sig(lib, "q3e_last_run_ms", c_float, [c_void_p])
@@ -83,9 +85,23 @@ def load(path: str | None = None):
     _sig(lib, "voc_set_exact_fp32", c_int, [c_int])
     _sig(lib, "voc_last_decode_ms", c_float, [c_void_p])
     _sig(lib, "voc_decode_flops", ctypes.c_double, [c_void_p, c_int])
-    # test hooks
-    _sig(lib, "q3t_device_count", c_int, [])
+    _sig(lib, "q3_device_count", c_int, [])
     _sig(lib, "q3_set_device", c_int, [c_int])
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def load_test():
+    """dlopen libqwen3tts_test.so: kernel-level hooks (csrc/q3_test_api.hip) for tests/ and bench.py.  The
+    product never calls this."""
+    global _test_lib
+    if _test_lib is not None:
+        return _test_lib
+    load()   # the product library first: the test library links against it
+    if not os.path.exists(TEST_LIB_PATH):
+        raise RuntimeError(f"{TEST_LIB_PATH} not found: build it with `python -m qwen3_tts_axera_russian_amd.build`")
+    lib = ctypes.CDLL(TEST_LIB_PATH)
     _sig(lib, "q3t_set_linear_tuning", c_int, [c_int, c_int, c_int])
     _sig(lib, "q3t_linear", c_int, [c_int, c_int, c_int, u16p, c_int, c_int, c_int, u16p, f32p, f32p, c_float,
                                     f32p, f32p, u16p, c_int])
@@ -95,8 +111,8 @@ def load(path: str | None = None):
     _sig(lib, "q3t_set_attn_short", c_int, [c_int])
     _sig(lib, "q3t_inspect_weights", c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, c_int])
     _sig(lib, "q3t_bench_linear", c_float, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int])
-    if path is None:
-        _lib = lib
+    _sig(lib, "q3t_bench_chain", c_float, [c_int, c_int, c_int, c_int, c_int, c_int])
+    _test_lib = lib
     return lib
 
 

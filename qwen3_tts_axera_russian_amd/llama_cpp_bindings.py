@@ -15,113 +15,107 @@ import numpy as np
 from . import LIB_DIR
 from . import hiplib
 
-# reference: llama_cpp_bindings.py:18-21 looks for llama_wrapper.so beside itself
-_WRAPPER_PATHS = [
-    os.path.join(LIB_DIR, "llama_wrapper.so"),
-    os.path.join(LIB_DIR, "libqwen3tts.so"),
-]
-
-
-def _load_wrapper():
-    for path in _WRAPPER_PATHS:
+def _talker_library():
+    """The wrapper_* ABI lives in lib/llama_wrapper.so -- the file name the reference's loader looks for beside
+    itself (dual_npu/llama_cpp_bindings.py:18-21) -- which is a copy of lib/libqwen3tts.so."""
+    for name in ("llama_wrapper.so", "libqwen3tts.so"):
+        path = os.path.join(LIB_DIR, name)
         if os.path.exists(path):
             return hiplib.load(path)
-    raise RuntimeError(f"llama_wrapper.so not found in {_WRAPPER_PATHS}")
-
-
-_lib = None
-
-
-def _get_lib():
-    global _lib
-    if _lib is None:
-        _lib = _load_wrapper()
-    return _lib
+    raise RuntimeError(f"no talker library (llama_wrapper.so / libqwen3tts.so) under {LIB_DIR}: "
+                       "run `python -m qwen3_tts_axera_russian_amd.build`; there is no CPU path")
 
 
 class LlamaCppModel:
-    """Talker in embedding mode: feeds codec/text embeddings, returns hidden states
-    (reference: llama_cpp_bindings.py:84-179)."""
+    """Talker in embeddings mode behind the wrapper_* ABI (include/qwen3tts_talker.h).
+
+    Public surface = the reference class of the same name (dual_npu/llama_cpp_bindings.py:84-179), because
+    llamacpp_talker_server.py drives it: get_hidden(emb, keep_history), clear_kv(), state_get_size(),
+    state_save(path), state_load(path), the read/write `pos` property (the server sets it after a KV-cache hit,
+    llamacpp_talker_server.py:231) and destroy().  Failures raise RuntimeError as there.  The position counter is
+    host bookkeeping only: the library honours whatever pos_start it is handed."""
+
+    #            method name      C symbol                     what a non-zero return means
+    _STATE_IO = {"state_save": ("wrapper_state_save_file", "saved"),
+                 "state_load": ("wrapper_state_load_file", "restored")}
 
     def __init__(self, model_path, n_ctx=512, n_threads=4):
-        lib = _get_lib()
-        self._lib = lib
-        lib.wrapper_backend_init()
-        self.model = lib.wrapper_load_model(str(model_path).encode(), 0)
+        self._abi = _talker_library()
+        self.model = self.ctx = None
+        self._abi.wrapper_backend_init()
+        self.model = self._abi.wrapper_load_model(os.fsencode(str(model_path)), 0)
         if not self.model:
-            raise RuntimeError(f"Failed to load model: {model_path}")
-        self.n_embd = lib.wrapper_model_n_embd(self.model)
-        assert self.n_embd > 0, f"n_embd={self.n_embd}"
-        self.ctx = lib.wrapper_create_context(self.model, n_ctx, n_ctx, n_threads, 1)  # embeddings=1
+            raise RuntimeError(f"talker weights could not be loaded from {model_path} (see stderr of the library)")
+        self.n_embd = int(self._abi.wrapper_model_n_embd(self.model))
+        if self.n_embd <= 0:
+            raise RuntimeError(f"library reports hidden size {self.n_embd}")
+        # n_batch = n_ctx and embeddings = 1, the values the reference passes (llama_cpp_bindings.py:100-104)
+        self.ctx = self._abi.wrapper_create_context(self.model, int(n_ctx), int(n_ctx), int(n_threads), 1)
         if not self.ctx:
-            raise RuntimeError("Failed to create llama context")
-        self.n_ctx = n_ctx
-        self._pos = 0
-        self._hidden_buf = np.zeros(self.n_embd, dtype=np.float32)
-        print(f"LlamaCppModel ready: n_embd={self.n_embd}, n_ctx={n_ctx}, backend=HIP/gfx950")
+            self.destroy()
+            raise RuntimeError(f"talker context of {n_ctx} positions could not be created")
+        self.n_ctx, self._pos = int(n_ctx), 0
+        self._out = np.empty(self.n_embd, dtype=np.float32)
+        print(f"LlamaCppModel (HIP, gfx950): hidden {self.n_embd}, context {self.n_ctx}")
 
+    # -- decode ----------------------------------------------------------------------------------------------
     def get_hidden(self, embeddings, keep_history=0):
-        """[n_tokens, n_embd] or [n_embd] float32 -> [n_embd] hidden of the last token.
-        keep_history: 0 = clear KV (prefill), 1 = append (decode step)."""
-        if keep_history == 0:
-            self._lib.wrapper_kv_clear(self.ctx)
-            self._pos = 0
-        embeddings = np.ascontiguousarray(embeddings, dtype=np.float32)
-        if embeddings.ndim == 1:
-            embeddings = embeddings.reshape(1, -1)
-        n_tokens = embeddings.shape[0]
-        assert embeddings.shape[1] == self.n_embd, f"Dim mismatch: {embeddings.shape[1]} vs {self.n_embd}"
-        ret = self._lib.wrapper_decode_embd(self.ctx, hiplib.fptr(embeddings), n_tokens, self.n_embd, self._pos,
-                                            hiplib.fptr(self._hidden_buf))
-        if ret != 0:
-            raise RuntimeError(f"wrapper_decode_embd failed: {ret}")
-        self._pos += n_tokens
-        return self._hidden_buf.copy()
+        """embeddings f32 [n, hidden] (or [hidden]) -> post-norm hidden [hidden] of the last row.
+        keep_history 0: the cache is cleared and the rows start at position 0 (prefill); 1: they are appended."""
+        rows = np.ascontiguousarray(embeddings, dtype=np.float32)
+        rows = rows.reshape(1, -1) if rows.ndim == 1 else rows
+        if rows.ndim != 2 or rows.shape[1] != self.n_embd:
+            raise AssertionError(f"embedding rows must be [n, {self.n_embd}], got {rows.shape}")
+        if not keep_history:
+            self.clear_kv()
+        rc = self._abi.wrapper_decode_embd(self.ctx, hiplib.fptr(rows), rows.shape[0], self.n_embd, self._pos,
+                                           hiplib.fptr(self._out))
+        if rc != 0:
+            raise RuntimeError(f"wrapper_decode_embd({rows.shape[0]} rows at position {self._pos}) returned {rc}")
+        self._pos += rows.shape[0]
+        return self._out.copy()
 
     def codec_head(self, hidden):
-        """Extension: codec_head GEMV on the device -> logits[talker_vocab]."""
+        """Extension (not in the reference class): codec_head GEMV on the device -> logits [rows, talker_vocab]."""
         hidden = np.ascontiguousarray(hidden, dtype=np.float32).reshape(-1, self.n_embd)
         out = np.empty((hidden.shape[0], 3072), np.float32)
-        v = self._lib.wrapper_codec_head(self.ctx, hiplib.fptr(hidden), hidden.shape[0], hiplib.fptr(out))
+        v = self._abi.wrapper_codec_head(self.ctx, hiplib.fptr(hidden), hidden.shape[0], hiplib.fptr(out))
         if v <= 0:
-            raise RuntimeError(f"wrapper_codec_head failed: {v}")
+            raise RuntimeError(f"wrapper_codec_head returned {v}")
         return out[:, :v] if v != 3072 else out
 
     def clear_kv(self):
-        self._lib.wrapper_kv_clear(self.ctx)
+        self._abi.wrapper_kv_clear(self.ctx)
         self._pos = 0
 
+    # -- KV state files (the server's prefix cache, llamacpp_talker_server.py:208-246) -------------------------
     def state_get_size(self):
-        return self._lib.wrapper_state_get_size(self.ctx)
+        return int(self._abi.wrapper_state_get_size(self.ctx))
+
+    def _state_io(self, which, path):
+        symbol, verb = self._STATE_IO[which]
+        rc = getattr(self._abi, symbol)(self.ctx, os.fsencode(str(path)))
+        if rc == 0:
+            print(f"  talker KV state {verb}: {path}" + (f" ({self._pos} positions)" if which == "state_save" else ""))
+        return rc
 
     def state_save(self, path):
-        ret = self._lib.wrapper_state_save_file(self.ctx, str(path).encode())
-        if ret == 0:
-            print(f"  KV state saved: {path} (pos={self._pos})")
-        return ret
+        return self._state_io("state_save", path)
 
     def state_load(self, path):
-        ret = self._lib.wrapper_state_load_file(self.ctx, str(path).encode())
-        if ret == 0:
-            print(f"  KV state loaded: {path}")
-        return ret
+        return self._state_io("state_load", path)
 
-    @property
-    def pos(self):
-        return self._pos
-
-    @pos.setter
-    def pos(self, value):
-        self._pos = value
+    pos = property(lambda self: self._pos, lambda self, value: setattr(self, "_pos", int(value)),
+                   doc="next position handed to wrapper_decode_embd (caller's bookkeeping, as in the reference)")
 
     def destroy(self):
+        abi = self._abi
         if self.ctx:
-            self._lib.wrapper_free_context(self.ctx)
-            self.ctx = None
+            abi.wrapper_free_context(self.ctx)
         if self.model:
-            self._lib.wrapper_free_model(self.model)
-            self.model = None
-        self._lib.wrapper_backend_free()
+            abi.wrapper_free_model(self.model)
+        self.ctx = self.model = None
+        abi.wrapper_backend_free()
 
 
 class CodePredictor:

@@ -16,7 +16,7 @@ def _gpu_available() -> bool:
     try:
         import ctypes
         from qwen3_tts_axera_russian_amd import LIB_PATH
-        return ctypes.CDLL(LIB_PATH).q3t_device_count() > 0
+        return ctypes.CDLL(LIB_PATH).q3_device_count() > 0
     except Exception:
         return False
 
@@ -27,9 +27,16 @@ def gpu_lib():
     extension is missing."""
     from qwen3_tts_axera_russian_amd import hiplib
     lib = hiplib.load()
-    if lib.q3t_device_count() <= 0:
+    if lib.q3_device_count() <= 0:
         pytest.fail("test marked gpu but no HIP device is visible")
     return lib
+
+
+@pytest.fixture(scope="session")
+def test_lib(gpu_lib):
+    """Kernel-level hooks (lib/libqwen3tts_test.so): tests only, never the product path."""
+    from qwen3_tts_axera_russian_amd import hiplib
+    return hiplib.load_test()
 
 
 @pytest.fixture(scope="session")

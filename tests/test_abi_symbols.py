@@ -18,7 +18,7 @@ def lib():
 def _declared(header):
     src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b((?:wrapper|cp|voc|q3e)_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b((?:wrapper|cp|voc|q3e|q3)_[a-z0-9_]+)\s*\(", src)))
 
 
 @pytest.mark.parametrize("header", ["qwen3tts_talker.h", "qwen3tts_cp.h", "qwen3tts_voc.h", "qwen3tts_engine.h"])
@@ -27,6 +27,23 @@ def test_every_declared_symbol_is_exported(lib, header):
     assert len(names) >= 5
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
+
+
+def test_test_hooks_are_not_in_the_product_library(lib):
+    """csrc/q3_test_api.hip (q3t_*) is built into lib/libqwen3tts_test.so, which links against the product
+    library; neither libqwen3tts.so nor its llama_wrapper.so copy carries a test or diagnostic hook."""
+    import subprocess
+    from qwen3_tts_axera_russian_amd import LIB_PATH, TEST_LIB_PATH
+    def exported(path):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+        return {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    prod = exported(LIB_PATH)
+    assert not [n for n in prod if n.startswith("q3t_")]
+    assert not [n for n in prod if "handoff" in n or "bench_chain" in n]
+    hooks = exported(TEST_LIB_PATH)
+    for n in ("q3t_linear", "q3t_talker_sample", "q3t_bench_linear", "q3t_inspect_weights"):
+        assert n in hooks
+    assert {"q3_device_count", "q3_set_device"} <= prod
 
 
 def test_reference_wrapper_names_present(lib):

@@ -37,17 +37,17 @@ def _norm_round(h, gamma, eps):
 
 @pytest.mark.parametrize("M", [1, 3, 16, 17, 32, 45, 64, 100])
 @pytest.mark.parametrize("N,K", [(4096, 1024), (1024, 2048), (1024, 3072), (3072, 1024)])
-def test_linear_store_f16(gpu_lib, M, N, K):
+def test_linear_store_f16(test_lib, M, N, K):
     rng = np.random.default_rng(M * 131 + N + K)
     W = _h(0.05 * rng.standard_normal((N, K)))
     x = _h(rng.standard_normal((M, K)))
     if K == 1024:
-        y, _, _ = _run_linear(gpu_lib, M, N, K, W, 0, 0, 0, x16=x, nt=M % 2)
+        y, _, _ = _run_linear(test_lib, M, N, K, W, 0, 0, 0, x16=x, nt=M % 2)
         ref = x.astype(np.float32) @ W.astype(np.float32).T
         np.testing.assert_allclose(y, ref, rtol=0, atol=2e-4 * np.abs(ref).max() + 1e-5)
     else:
         h0 = rng.standard_normal((M, N)).astype(np.float32)
-        y, ssq, _ = _run_linear(gpu_lib, M, N, K, W, 0, 0, 1, x16=x, h_io=h0, nt=M % 2)
+        y, ssq, _ = _run_linear(test_lib, M, N, K, W, 0, 0, 1, x16=x, h_io=h0, nt=M % 2)
         ref = h0 + x.astype(np.float32) @ W.astype(np.float32).T
         np.testing.assert_allclose(y, ref, rtol=0, atol=2e-4 * np.abs(ref).max() + 1e-5)
         ref_ssq = (ref.astype(np.float64) ** 2).reshape(M, N // 16, 16).sum(-1)
@@ -55,7 +55,7 @@ def test_linear_store_f16(gpu_lib, M, N, K):
 
 
 @pytest.mark.parametrize("M", [1, 7, 16, 32, 40])
-def test_linear_norm_prologue_and_swiglu(gpu_lib, M):
+def test_linear_norm_prologue_and_swiglu(test_lib, M):
     rng = np.random.default_rng(900 + M)
     K, F = 1024, 3072
     h = (3.0 * rng.standard_normal((M, K))).astype(np.float32)
@@ -63,20 +63,20 @@ def test_linear_norm_prologue_and_swiglu(gpu_lib, M):
     xr = _norm_round(h, gamma, 1e-6).astype(np.float32)
     # q/k/v-shaped store
     W = _h(0.05 * rng.standard_normal((4096, K)))
-    y, _, _ = _run_linear(gpu_lib, M, 4096, K, W, 0, 1, 0, h=h, gamma=gamma)
+    y, _, _ = _run_linear(test_lib, M, 4096, K, W, 0, 1, 0, h=h, gamma=gamma)
     ref = xr @ W.astype(np.float32).T
     # a norm-input rounding flip (1 fp16 ulp on one element) moves an output by <= 2^-11*|x|*|w|
     np.testing.assert_allclose(y, ref, rtol=0, atol=1e-3 * np.abs(ref).max())
     # gate/up + SwiGLU; weights: rows [0,F) gate, [F,2F) up
     Wgu = _h(0.05 * rng.standard_normal((2 * F, K)))
-    _, _, act = _run_linear(gpu_lib, M, 2 * F, K, Wgu, 1, 1, 2, h=h, gamma=gamma)
+    _, _, act = _run_linear(test_lib, M, 2 * F, K, Wgu, 1, 1, 2, h=h, gamma=gamma)
     g = xr @ Wgu[:F].astype(np.float32).T
     u = xr @ Wgu[F:].astype(np.float32).T
     ref_act = (g / (1.0 + np.exp(-g))) * u
     np.testing.assert_allclose(act.astype(np.float32), ref_act, rtol=2e-3, atol=2e-3 * np.abs(ref_act).max())
 
 
-def test_linear_exact_integer_layout(gpu_lib):
+def test_linear_exact_integer_layout(test_lib):
     """Asymmetric small-integer operands: every product and sum is exact, so any fragment-layout
     mistake (row/col swap, k permutation) shows up as a hard mismatch."""
     M, N, K = 19, 1024, 2048
@@ -84,5 +84,5 @@ def test_linear_exact_integer_layout(gpu_lib):
     W = rng.integers(-3, 4, size=(N, K)).astype(np.float16)
     x = rng.integers(-2, 3, size=(M, K)).astype(np.float16)
     h0 = np.zeros((M, N), np.float32)
-    y, _, _ = _run_linear(gpu_lib, M, N, K, W, 0, 0, 1, x16=x, h_io=h0)
+    y, _, _ = _run_linear(test_lib, M, N, K, W, 0, 0, 1, x16=x, h_io=h0)
     np.testing.assert_array_equal(y, x.astype(np.float32) @ W.astype(np.float32).T)

@@ -1,0 +1,162 @@
+"""Misuse and bad-input cases of the public C ABI that must neither fault the GPU nor corrupt results
+(round-1 review items): sampler top_k edge values and non-finite logits, stepping the engine past its frame
+budget, a vocoder chunk length the overlap walk cannot handle."""
+import numpy as np
+import pytest
+
+from qwen3_tts_axera_russian_amd import hiplib
+from qwen3_tts_axera_russian_amd.engine import FrameEngine
+from qwen3_tts_axera_russian_amd.llama_cpp_bindings import CodePredictor
+from tests.util import synthetic_pack
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pack():
+    return synthetic_pack(2, 2)
+
+
+@pytest.mark.parametrize("top_k", [0, -3, 1, 50, 64, 65, 500, 2048, 100000])
+def test_cp_sampler_top_k_edge_values(gpu_lib, pack, top_k):
+    """top_k <= 0 or >= vocabulary = every entry (the reference's samplers: code_predictor_server.py:87-92);
+    values beyond the 64-entry selection path take the full-sort path; all must return ids in range and be
+    reproducible for a seed."""
+    path, cfg, _ = pack
+    cp = CodePredictor(path, max_batch=4)
+    rng = np.random.default_rng(3)
+    hid = (0.5 * rng.standard_normal((4, 1024))).astype(np.float32)
+    c0 = np.array([5, 100, 2047, 900], np.int32)
+    a = cp.predict_batch(hid, c0, temperature=0.9, top_k=top_k, seed=11)
+    b = cp.predict_batch(hid, c0, temperature=0.9, top_k=top_k, seed=11)
+    c = cp.predict_batch(hid, c0, temperature=0.9, top_k=top_k, seed=12)
+    greedy = cp.predict_batch(hid, c0, temperature=0.0, top_k=top_k, seed=0)
+    cp.destroy()
+    assert ((a >= 0) & (a < 2048)).all()
+    np.testing.assert_array_equal(a, b)
+    if top_k == 1:
+        np.testing.assert_array_equal(a, greedy)          # one candidate: the draw is the arg-max
+    else:
+        assert (a != c).any()                               # another seed, another stream
+
+
+def test_cp_wide_top_k_distribution_matches_softmax(gpu_lib, pack):
+    """top_k = all at a high temperature: the first group's empirical distribution over many seeds follows
+    softmax(logits / T) of the same logits (total-variation distance of the 20 most likely ids < 0.08)."""
+    path, cfg, _ = pack
+    cp = CodePredictor(path, max_batch=32)
+    rng = np.random.default_rng(5)
+    hid1 = (0.5 * rng.standard_normal(1024)).astype(np.float32)
+    hid = np.tile(hid1, (32, 1))
+    c0 = np.full(32, 77, np.int32)
+    T = 0.5
+    draws = np.concatenate([cp.predict_batch(hid, c0, temperature=T, top_k=0, seed=1000 + s)[:, 0] for s in range(40)])
+    # logits of group 0 for this input: position 0 and 1 through the stack, then head 0
+    cp1 = CodePredictor(path, max_batch=1)
+    cp1.step(hid1, 0)
+    from qwen3_tts_axera_russian_amd import weights as W
+    _, tensors = W.read_pack(path)
+    h1 = cp1.step(np.asarray(tensors["talker.codec_embedding"][77], np.float32), 1)
+    logits = cp1.lm_head(0, h1).astype(np.float64)
+    cp1.destroy()
+    cp.destroy()
+    p = np.exp((logits - logits.max()) / T)
+    p /= p.sum()
+    top = np.argsort(-p)[:20]
+    emp = np.array([(draws == t).mean() for t in top])
+    tv = 0.5 * np.abs(emp - p[top]).sum()
+    print("empirical vs softmax on the 20 likeliest ids: TV", tv, "mass", p[top].sum())
+    assert tv < 0.08
+
+
+def test_talker_sampler_survives_non_finite_logits(test_lib):
+    """A row of NaN / -inf logits must not make the sampler index LDS out of bounds: greedy answers like numpy's
+    argmax (first NaN wins -> that id is outside the audio range -> the utterance ends)."""
+    V = 3072
+    for fill in (np.nan, -np.inf):
+        lg = np.full(V, fill, np.float32)
+        got = test_lib.q3t_talker_sample(hiplib.fptr(lg), V, hiplib.iptr(np.zeros(1, np.int32)), 0, 10, 0)
+        assert got == -1 or 0 <= got < 2048
+    lg = np.zeros(V, np.float32)
+    lg[123] = np.nan                      # a NaN among finite logits wins, as in np.argmax
+    assert test_lib.q3t_talker_sample(hiplib.fptr(lg), V, hiplib.iptr(np.zeros(1, np.int32)), 0, 10, 0) == 123
+
+
+def test_engine_sampling_with_nan_weights_does_not_fault(gpu_lib, pack, tmp_path):
+    """Stochastic sampling over rows whose logits are all NaN (a corrupted head): the run completes with ids
+    in range or finished rows -- no out-of-bounds selection."""
+    from qwen3_tts_axera_russian_amd import weights as W
+    path, cfg, tensors = pack
+    t = {k: np.array(v) for k, v in tensors.items()}
+    t["cp.lm_head.3"] = np.full_like(t["cp.lm_head.3"], np.nan)
+    bad = str(tmp_path / "nan_head.q3w")
+    meta, _ = W.read_pack(path)
+    W.write_pack(bad, meta, t)
+    eng = FrameEngine(bad, max_batch=2, n_ctx=64, max_frames=8)
+    eng.set_sampling(0.8, 50, 0.95, 0.8, 0, seed=5)
+    rng = np.random.default_rng(2)
+    eng.start([(0.05 * rng.standard_normal((n, 1024))).astype(np.float32) for n in (10, 14)], [20, 20],
+              ignore_eos=True, max_frames=8)
+    assert eng.run(8) == 8
+    codes, per = eng.codes()
+    assert ((codes >= -1) & (codes < 2048)).all()
+    eng.destroy()
+
+
+def test_engine_run_past_its_frame_budget_changes_nothing(gpu_lib, pack):
+    """q3e_run clamps to the frames the batch was started for: a further call returns 0 and the last recorded
+    frame keeps its codes (round 1 overwrote it with -1 / a finished row's values)."""
+    path, cfg, _ = pack
+    rng = np.random.default_rng(9)
+    eng = FrameEngine(path, max_batch=2, n_ctx=64, max_frames=6)
+    eng.start([(0.05 * rng.standard_normal((n, 1024))).astype(np.float32) for n in (9, 12)], [30, 30],
+              ignore_eos=True, max_frames=6)
+    assert eng.run(100) == 6              # asked for 100, the budget is 6
+    codes, per = eng.codes()
+    before = codes.copy()
+    assert (before[:, :, 0] >= 0).all() and list(per) == [6, 6]
+    assert eng.run(1) == 0 and eng.run(5) == 0
+    codes2, per2 = eng.codes()
+    np.testing.assert_array_equal(codes2, before)
+    assert list(per2) == [6, 6]
+    eng.destroy()
+
+
+def test_engine_requests_draw_from_different_streams(gpu_lib, pack):
+    """One seed, two requests with the same inputs: the second request must not replay the first one's draws
+    (a server sets the seed once), while a fresh engine with the same seed reproduces the first."""
+    path, cfg, _ = pack
+    rng = np.random.default_rng(4)
+    pre = [(0.05 * rng.standard_normal((n, 1024))).astype(np.float32) for n in (10, 13)]
+    outs = []
+    for _ in range(2):
+        eng = FrameEngine(path, max_batch=2, n_ctx=64, max_frames=8)
+        eng.set_sampling(0.9, 50, 0.95, 0.9, 50, seed=21)
+        seq = []
+        for _req in range(2):
+            eng.start(pre, [30, 30], ignore_eos=True, max_frames=8)
+            eng.run(8)
+            seq.append(eng.codes()[0].copy())
+        eng.destroy()
+        outs.append(seq)
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])      # reproducible per (seed, request index)
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    assert (outs[0][0] != outs[0][1]).any()                    # but request 2 is not a replay of request 1
+
+
+def test_voc_load_rejects_chunks_the_overlap_walk_cannot_step(gpu_lib, tmp_path):
+    from qwen3_tts_axera_russian_amd import weights as W
+    vp = str(tmp_path / "v.q3w")
+    W.write_pack(vp, {"voc_chunk": 64.0}, W.make_synthetic_voc(W.tiny_voc_config(), seed=7))
+    for bad in (1, 16, 32):
+        assert not gpu_lib.voc_load(vp.encode(), bad, 1)
+    h = gpu_lib.voc_load(vp.encode(), 48, 1)
+    assert h
+    n = 100
+    codes = np.random.default_rng(0).integers(0, 2048, size=(n, 16)).astype(np.int64)
+    cap = gpu_lib.voc_synthesize_max_samples(h, n)
+    out = np.empty(cap, np.float32)
+    ns = np.zeros(1, np.int32)
+    assert gpu_lib.voc_synthesize_f32(h, codes.ctypes.data_as(hiplib.i64p), n, hiplib.fptr(out), hiplib.iptr(ns)) == 0
+    assert 0 < int(ns[0]) <= cap
+    gpu_lib.voc_free(h)

@@ -23,7 +23,7 @@ def _device_sample(lib, logits, past, n_text):
     return lib.q3t_talker_sample(hiplib.fptr(logits), len(logits), hiplib.iptr(p), len(past), int(n_text), 0)
 
 
-def test_device_sampler_matches_reference_outputs(gpu_lib, golden):
+def test_device_sampler_matches_reference_outputs(test_lib, golden):
     head = _codec_head(golden)
     n = int(golden["sample_n"])
     ended = 0
@@ -32,10 +32,10 @@ def test_device_sampler_matches_reference_outputs(gpu_lib, golden):
         past = [int(x) for x in golden[f"sample_{ci}_past"]]
         n_text = int(golden[f"sample_{ci}_ntext"])
         ref_tok = int(golden[f"sample_{ci}_tok"])
-        got = _device_sample(gpu_lib, hidden @ head.T, past, n_text)
+        got = _device_sample(test_lib, hidden @ head.T, past, n_text)
         want = -1 if (ref_tok == 2150 or ref_tok >= 2048) else ref_tok
         assert got == want, f"case {ci}: device {got}, reference {ref_tok}"
         ended += want == -1
     assert ended >= 1
-    got = _device_sample(gpu_lib, golden["sample_rep_hidden"] @ head.T, [int(x) for x in golden["sample_rep_past"]], 50)
+    got = _device_sample(test_lib, golden["sample_rep_hidden"] @ head.T, [int(x) for x in golden["sample_rep_past"]], 50)
     assert got == int(golden["sample_rep_tok"])

@@ -179,3 +179,40 @@ def test_native_cp_server_binary(gpu_lib, packs, tmp_path):
     assert proc.returncode == 0, text
     assert "warmup result" in text and "Server stopped." in text
     assert not os.path.exists(sock)
+
+
+def test_launcher_starts_trio_and_tears_down(gpu_lib, packs, tmp_path):
+    """The per-GPU launcher (the reference's launch_qwen3_tts.sh:70-104,134-190): --daemon starts the three servers
+    as processes pinned with HIP_VISIBLE_DEVICES, their per-GPU sockets appear while the launcher watches the pids,
+    a request goes through, SIGTERM tears everything down and removes the sockets."""
+    import signal
+    import subprocess
+    import sys
+    main, voc, cfg = packs
+    gpu = 0
+    socks = [f"/tmp/qwen3_{k}_gpu{gpu}.sock" for k in ("talker", "cp", "voc")]
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    log = open(tmp_path / "launcher.log", "w")
+    p = subprocess.Popen([sys.executable, "-m", "qwen3_tts_axera_russian_amd.launch_qwen3_tts", "--weights", main,
+                          "--vocoder", voc, "--gpu", str(gpu), "--temperature", "0", "--cp_temperature", "0",
+                          "--max_tokens", "12", "--daemon"], env=env, stdout=log, stderr=subprocess.STDOUT)
+    try:
+        t0 = time.time()
+        while not all(os.path.exists(s) for s in socks):
+            assert p.poll() is None, f"launcher exited early ({p.returncode}): {open(tmp_path / 'launcher.log').read()[-2000:]}"
+            assert time.time() - t0 < 300, "sockets did not appear"
+            time.sleep(0.2)
+        from qwen3_tts_axera_russian_amd.tts_client import Qwen3TTSClient
+        client = Qwen3TTSClient(*socks, weights=main)
+        codes, audio = client.synthesize("ignored", "russian", str(tmp_path / "l.wav"), streaming=False,
+                                         token_ids=[5, 17, 200, 33, 41, 7])
+        assert 1 <= codes.shape[0] <= 12 and len(audio) == codes.shape[0] * 1920
+    finally:
+        p.send_signal(signal.SIGTERM)
+        try:
+            p.wait(timeout=60)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            raise
+    assert p.returncode == 1                       # the launcher's SIGTERM path (cleanup, then exit 1)
+    assert not any(os.path.exists(s) for s in socks)

@@ -22,7 +22,7 @@ def fnv1a(b: bytes) -> int:
 
 
 def inspect(path, aux=None):
-    lib = hiplib.load()
+    lib = hiplib.load_test()
     buf = ctypes.create_string_buffer(1 << 20)
     n = lib.q3t_inspect_weights(str(path).encode(), str(aux).encode() if aux else None, buf, len(buf))
     if n < 0:
