@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X Qwen3-TTS hot path (BASELINE.json metric: RTF + 12 Hz codec-tokens/s).
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process IS a
+rank; started plainly with --gpus N it first re-launches itself as N ranks through torch.distributed.run (before
+anything touches a GPU) and relays rank 0's JSON line.
 
 One "step" = one pass of the hot path over one batch of synthetic utterances: ragged prefill of B
 prompts + F autoregressive frames (talker step, 15-group code predictor, feedback) for all of them
@@ -9,8 +13,10 @@ prompts + F autoregressive frames (talker step, 15-group code predictor, feedbac
 step i runs on its own stream while the frame loop of step i+1 proceeds (the streaming overlap of the
 reference client, tts_client.py:188-197).  Weights and prefix embeddings are resident before the
 timed region.  Utterances are independent:
-N GPUs = N replicas of the per-GPU batch, no collective on the data path (weak scaling); the only
-torch.distributed traffic is the barrier and the max-over-ranks of the elapsed time.
+the N*B utterances of a job (config 4: 256 = the 32 prompts x 8) are sorted by expected length (3 frames per
+text token, the reference's own estimate: llamacpp_talker_server.py:174) and dealt round-robin to the N ranks; no
+collective on the data path (weak scaling); the only torch.distributed traffic is the barrier and the
+max-over-ranks of the elapsed time.
 
 Prints ONE JSON line on rank 0.  Weights are random-init tensors of the Qwen3-TTS-0.6B architecture
 (no checkpoint can exist here), decode is greedy with EOS suppressed so the frame count is fixed.
@@ -51,6 +57,11 @@ def parse():
     ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 latency leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-frames", type=int, default=96, help="frames of the CPU baseline sample (~12 s at 8 frames/s)")
+    ap.add_argument("--backend", default=os.environ.get("Q3_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="process-group backend (nccl = RCCL; gloo only for the CPU test of the rank logic)")
+    ap.add_argument("--stub-engine", action="store_true", default=os.environ.get("Q3_BENCH_STUB", "") not in ("", "0"),
+                    help="CPU test of the launch/rank/dealing logic: a stand-in engine that computes nothing "
+                         "(the line is marked data=stub and is not a measurement)")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--cache", default=os.environ.get("Q3_BENCH_CACHE", "/tmp/q3_bench_cache"))
     return ap.parse_args()
@@ -79,13 +90,50 @@ def make_voc_pack(cache, seed, rank, barrier):
     return path
 
 
-def workload(B, rank, seed):
-    """B prompts of the fixed set (offset by rank): prefix rows = n_text + 9 (llamacpp_talker_server.py:121-161)."""
-    rng = np.random.default_rng(seed + 1000 * rank)
-    n_text = [PROMPT_TOKENS[(rank * B + b) % len(PROMPT_TOKENS)] for b in range(B)]
-    prefixes = [(0.03 * rng.standard_normal((n + 9, 1024))).astype(np.float32) for n in n_text]
-    pad = (0.03 * rng.standard_normal(1024)).astype(np.float32)
+def deal(n_text_all, world):
+    """Utterance indices of every rank: sort the job's utterances by expected length (3 frames per text token,
+    llamacpp_talker_server.py:174; ties by index), deal round-robin.  Every rank gets the same
+    count (+-1) and the same mix of short and long utterances; no rank waits on a batch of long ones."""
+    order = sorted(range(len(n_text_all)), key=lambda i: (-3 * n_text_all[i], i))
+    return [order[r::world] for r in range(world)]
+
+
+def workload(B, rank, seed, world=1):
+    """This rank's B utterances of the job's world*B (the fixed prompt set, repeated): prefix rows = n_text + 9
+    (llamacpp_talker_server.py:121-161).  Every utterance has its own seeded embeddings, whatever rank runs it."""
+    total = world * B
+    n_text_all = [PROMPT_TOKENS[i % len(PROMPT_TOKENS)] for i in range(total)]
+    mine = deal(n_text_all, world)[rank]
+    n_text = [n_text_all[i] for i in mine]
+    prefixes = [(0.03 * np.random.default_rng(seed + 7919 * i).standard_normal((n_text_all[i] + 9, 1024))).astype(np.float32)
+                for i in mine]
+    pad = (0.03 * np.random.default_rng(seed + 1000 * rank).standard_normal(1024)).astype(np.float32)
     return prefixes, n_text, pad
+
+
+class StubEngine:
+    """Stand-in for FrameEngine in the CPU test of the launch / rank / dealing logic (--stub-engine): same calls,
+    no computation.  A line produced with it says data=stub."""
+    last_prefill_ms, step_weight_bytes = 0.01, 3.467e9
+
+    def __init__(self, *_, **kw):
+        self.max_frames, self.B, self.last_run_ms = kw.get("max_frames", 64), 0, 0.0
+
+    def set_pad_embed(self, pad): pass
+    def set_chains(self, n): pass
+
+    def start(self, prefixes, n_text, ignore_eos=False, max_frames=0):
+        self.B = len(prefixes)
+
+    def run(self, n):
+        time.sleep(1e-4 * n)
+        self.last_run_ms = 0.1 * n
+        return n
+
+    def codes(self):
+        return np.zeros((self.max_frames, self.B, 16), np.int32), np.full(self.B, self.max_frames, np.int32)
+
+    def destroy(self): pass
 
 
 class Vocoder:
@@ -171,9 +219,9 @@ def dominant_kernel_roofline(lib, rows):
     (12.58 MB of fp16 weights, 36 % of a layer's stream).  Timed live: back-to-back launches over 48
     distinct weight copies (cold, like the layer walk), HIP events on the launch stream."""
     import ctypes
-    lib.q3t_bench_linear.restype = ctypes.c_float
+    from qwen3_tts_axera_russian_amd import hiplib
     N, K = 6144, 1024
-    us = float(lib.q3t_bench_linear(int(rows), N, K, 1, 2, 1, 48, 480))
+    us = float(hiplib.load_test().q3t_bench_linear(int(rows), N, K, 1, 2, 1, 48, 480))
     algo = N * K * 2 + rows * K * 4 + rows * (N // 2) * 2      # weights + f32 activations in + fp16 out
     ach = algo / (us * 1e-6) / 1e9
     return {"kernel": "linear_kernel<gate/up+SwiGLU> (RMSNorm prologue, MFMA 16x16x32 f16, split-K over waves)",
@@ -263,11 +311,47 @@ def aggregate_value(world, B, frames, steps, dt_max):
     return world * B * frames * steps / dt_max
 
 
+def relaunch_as_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) through torch.distributed.run
+    BEFORE this process touches a GPU, relay their output (rank 0 prints the JSON line) and exit with their code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
-    R = Ranks("nccl")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_as_ranks(a.gpus))
+    R = Ranks(a.backend)
     rank, world, local_rank, dist = R.rank, R.world, R.local_rank, R.dist
     barrier = R.barrier
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s)")
+
+    sync_all = R.sync_all  # engine calls are synchronous (every q3e_run ends with a stream sync)
+    B, F = a.batch, a.frames
+    prefixes, n_text, pad = workload(B, rank, a.seed, world)
+    if a.stub_engine:
+        eng = StubEngine(max_frames=F)
+        dt, frame_ms, _, _ = run_leg(eng, None, prefixes, n_text, pad, F, a.steps, a.warmup, sync_all)
+        dt = R.max_over_ranks(dt)
+        if rank == 0:
+            print(json.dumps({"metric": "12Hz codec-tokens/s (codec frames/s, 16 codes each) + RTF, Qwen3-TTS-0.6B",
+                              "value": round(aggregate_value(world, B, F, a.steps, dt), 1), "unit": "codec_frames/s",
+                              "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                              "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                              "vs_baseline": None, "dtype": "none", "data": "stub (no computation: launch-logic test)",
+                              "config": {"workload": "stub", "batch_per_gpu": B, "frames_per_step": F,
+                                         "n_text_rank0": n_text}}), flush=True)
+        R.close()
+        return
 
     from qwen3_tts_axera_russian_amd import hiplib
     from qwen3_tts_axera_russian_amd.engine import FrameEngine
@@ -276,11 +360,7 @@ def main():
         raise SystemExit("bench.py: no HIP device -- the HIP library is the only compute path")
     lib.q3_set_device(local_rank % lib.q3_device_count())
 
-    sync_all = R.sync_all  # engine calls are synchronous (every q3e_run ends with a stream sync)
-
     path, cfg = make_pack(a.cache, a.seed, rank, barrier)
-    B, F = a.batch, a.frames
-    prefixes, n_text, pad = workload(B, rank, a.seed)
     n_ctx = max(p.shape[0] for p in prefixes) + F + 8
     eng = FrameEngine(path, max_batch=B, n_ctx=n_ctx, max_frames=F)
     if a.chains > 0:
@@ -292,6 +372,9 @@ def main():
         if a.voc_wgs >= 0:
             lib.voc_set_max_workgroups(a.voc_wgs)
         voc = Vocoder(lib, make_voc_pack(a.cache, a.seed, rank, barrier), B)
+        # headline arithmetic = exact fp32 (north_star: "fused fp32 HIP kernel"); the 2 x fp16 split-operand mode
+        # (fp32-grade against float64) is reported beside it as an option
+        lib.voc_set_exact_fp32(1)
     dt, frame_ms_step, prefill_ms, voc_ms = run_leg(eng, voc, prefixes, n_text, pad, F, a.steps, a.warmup, sync_all)
     # the frame graph alone on the chip (inside a step the previous step's vocoder chunk runs beside it and the two
     # split the machine: the step time is their sum either way, the kernel-quality figure is this one)
@@ -313,7 +396,7 @@ def main():
         "metric": "12Hz codec-tokens/s (codec frames/s, 16 codes each) + RTF, Qwen3-TTS-0.6B",
         "value": round(value, 1), "unit": "codec_frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16 weights/KV, f32 accumulate (talker+CP); vocoder f32 via 2xf16 split operands, f32 accumulate", "data": "synthetic (random-init weights of the "
+        "dtype": "f16 weights/KV, f32 accumulate (talker+CP); vocoder exact fp32 (f32 MFMA)", "data": "synthetic (random-init weights of the "
         "0.6B architecture, seeded prefix embeddings, greedy, EOS suppressed)",
         "config": {"workload": f"configs[2]/[3]: batch={B} mixed ru/en prompts per GPU, {F} frames/utterance/step "
                                f"(prefill + hipGraph decode loop), utterance-sharded DP over {world} GPU(s)",
@@ -330,38 +413,27 @@ def main():
     }
     if voc is not None:
         fl = float(lib.voc_decode_flops(voc.h, B))
-        if os.environ.get("Q3_VOC_EXACT", "0") not in ("", "0"):
-            out["roofline_vocoder"] = {"kernel": "conv_kernel (exact-fp32 MFMA implicit-GEMM conv stack, whole chunk)",
-                                       "bound": "mfma", "achieved": round(fl / (voc_ms * 1e-3) / 1e12, 2),
-                                       "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                       "frac": round(fl / (voc_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                                       "traffic": None, "flops_per_launch": fl, "avg_launch_ms": round(voc_ms, 3)}
-        else:
-            # default arithmetic: every f32 operand as two fp16 terms, 3 fp16 MFMAs per product, f32 accumulate
-            # (fp32-grade against float64: tests/test_gpu_vocoder.py); executed MFMA flops = 3 x table flops
-            mf = 3.0 * fl
-            out["roofline_vocoder"] = {"kernel": "conv_split_kernel (2xfp16 split operands, 3 fp16 MFMAs per product, "
-                                                 "f32 accumulate; whole conv stack of a chunk)",
-                                       "bound": "mfma", "achieved": round(mf / (voc_ms * 1e-3) / 1e12, 2),
-                                       "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                       "frac": round(mf / (voc_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
-                                       "traffic": None, "flops_per_launch": mf,
-                                       "fp32_equivalent_tflops": round(fl / (voc_ms * 1e-3) / 1e12, 2),
-                                       "avg_launch_ms": round(voc_ms, 3),
-                                       "avg_launch_ms_beside_frame_loop": round(voc_ms_step, 3)}
-        # the same vocoder with the exact-fp32 MFMA arithmetic (Q3_VOC_EXACT=1), for whoever prices the default
-        # split arithmetic as something other than fp32: one decode alone, and two whole steps (rank 0, N = 1)
-        if world == 1 and os.environ.get("Q3_VOC_EXACT", "0") in ("", "0"):
-            lib.voc_set_exact_fp32(1)
-            voc.decode(codes_alone.copy())
-            ex_ms = float(voc.ms[-1])
-            dt_ex, _, _, _ = run_leg(eng, voc, prefixes, n_text, pad, F, 2, 1, sync_all)
+        out["roofline_vocoder"] = {"kernel": "conv_kernel (exact-fp32 MFMA implicit-GEMM conv stack, whole chunk batch)",
+                                   "bound": "mfma", "achieved": round(fl / (voc_ms * 1e-3) / 1e12, 2),
+                                   "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(fl / (voc_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                   "traffic": None, "flops_per_launch": fl, "avg_launch_ms": round(voc_ms, 3),
+                                   "avg_launch_ms_beside_frame_loop": round(voc_ms_step, 3)}
+        # the optional arithmetic: every f32 operand as two fp16 terms, 3 fp16 MFMAs per product, f32 accumulate
+        # (executed MFMA flops = 3 x table flops): one decode alone, and two whole steps (rank 0, N = 1)
+        if world == 1:
             lib.voc_set_exact_fp32(0)
-            out["vocoder_exact_fp32"] = {"avg_launch_ms": round(ex_ms, 3), "achieved": round(fl / (ex_ms * 1e-3) / 1e12, 2),
-                                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                         "frac": round(fl / (ex_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                                         "value_with_exact_vocoder": round(aggregate_value(1, B, F, 2, dt_ex), 1),
-                                         "ms_per_step_with_exact_vocoder": round(dt_ex / 2 * 1e3, 3)}
+            voc.decode(codes_alone.copy())
+            sp_ms = float(voc.ms[-1])
+            dt_sp, _, _, _ = run_leg(eng, voc, prefixes, n_text, pad, F, 2, 1, sync_all)
+            lib.voc_set_exact_fp32(1)
+            out["vocoder_split_f16x2"] = {"avg_launch_ms": round(sp_ms, 3),
+                                          "achieved": round(3.0 * fl / (sp_ms * 1e-3) / 1e12, 2),
+                                          "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                          "frac": round(3.0 * fl / (sp_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+                                          "fp32_equivalent_tflops": round(fl / (sp_ms * 1e-3) / 1e12, 2),
+                                          "value_with_split_vocoder": round(aggregate_value(1, B, F, 2, dt_sp), 1),
+                                          "ms_per_step_with_split_vocoder": round(dt_sp / 2 * 1e3, 3)}
         voc.close()
     eng.destroy()
     if world == 1 and not a.no_b1:

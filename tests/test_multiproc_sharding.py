@@ -1,6 +1,9 @@
-"""The N>1 path of bench.py on CPU: two processes over gloo exercise the rank bookkeeping, the
-utterance sharding (disjoint prompt slices, no data-path collective) and the max-over-ranks timing."""
+"""The N>1 path of bench.py on CPU (gloo, world size 2): rank bookkeeping, the length-sorted round-robin dealing of
+utterances (no data-path collective), the max-over-ranks timing, and `python bench.py --gpus 2` starting its two
+ranks itself."""
+import json
 import os
+import subprocess
 import sys
 
 import torch.multiprocessing as mp
@@ -14,11 +17,11 @@ def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import bench
     R = bench.Ranks("gloo")
-    prefixes, n_text, pad = bench.workload(4, R.rank, 1234)
+    prefixes, n_text, pad = bench.workload(4, R.rank, 1234, R.world)
     R.barrier()
     dt = R.max_over_ranks(1.0 + R.rank)           # rank 1 is the slow one
     R.sync_all()
-    q.put((R.rank, R.world, n_text, [p.shape for p in prefixes], dt, float(pad[0])))
+    q.put((R.rank, R.world, n_text, [p.shape for p in prefixes], dt, float(prefixes[0][0, 0])))
     R.close()
 
 
@@ -33,12 +36,51 @@ def test_two_ranks_shard_prompts_and_reduce_time():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, w0, t0, s0, dt0, pad0), (r1, w1, t1, s1, dt1, pad1) = res
+    (r0, w0, t0, s0, dt0, x0), (r1, w1, t1, s1, dt1, x1) = res
     assert (r0, r1, w0, w1) == (0, 1, 2, 2)
     assert dt0 == dt1 == 2.0                       # both ranks see the max
     sys.path.insert(0, ROOT)
     import bench
-    assert t0 == bench.PROMPT_TOKENS[0:4] and t1 == bench.PROMPT_TOKENS[4:8]   # disjoint consecutive slices
+    # 8 utterances (prompts 0..7), sorted by 3 * n_text descending, dealt 0,1,0,1,...
+    order = sorted(range(8), key=lambda i: (-bench.PROMPT_TOKENS[i], i))
+    assert t0 == [bench.PROMPT_TOKENS[i] for i in order[0::2]]
+    assert t1 == [bench.PROMPT_TOKENS[i] for i in order[1::2]]
+    assert sorted(t0 + t1) == sorted(bench.PROMPT_TOKENS[:8])          # a partition: nothing twice, nothing lost
     assert all(s == (n + 9, 1024) for s, n in zip(s0, t0))
-    assert pad0 != pad1                            # per-rank seeds differ
+    assert x0 != x1                                # utterances carry their own seeds
     assert bench.aggregate_value(2, 32, 64, 6, 2.0) == 2 * 32 * 64 * 6 / 2.0
+
+
+def test_dealing_balances_config4():
+    """BASELINE config 4: 256 utterances over 8 ranks -> 32 each, identical length mix on every rank."""
+    sys.path.insert(0, ROOT)
+    import bench
+    n_all = [bench.PROMPT_TOKENS[i % 32] for i in range(256)]
+    d = bench.deal(n_all, 8)
+    assert sorted(i for r in d for i in r) == list(range(256))
+    assert all(len(r) == 32 for r in d)
+    loads = [sum(n_all[i] for i in r) for r in d]
+    assert max(loads) == min(loads)
+    ragged = bench.deal([5, 40, 7, 33, 21, 9, 30], 3)                   # counts differ by at most one
+    assert sorted(len(r) for r in ragged) == [2, 2, 3]
+
+
+def test_bench_gpus_2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher environment must run TWO ranks (round 1 ran one and printed
+    n_gpus 1).  CPU: gloo backend and the stand-in engine; the JSON line must say n_gpus 2 and count both ranks'
+    frames."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--batch", "4", "--frames", "8", "--stub-engine", "--backend", "gloo"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout                                  # rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["data"].startswith("stub")
+    assert abs(j["value"] - 2 * 4 * 8 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 1e-3
+    # a mismatch between --gpus and the launched world is an error, not a silent 1-GPU run
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub-engine", "--backend", "gloo"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0
