@@ -73,8 +73,16 @@ def lib():
                                      ctypes.POINTER(c_float_p), ctypes.c_int, ctypes.c_int, c_float_p,
                                      ctypes.c_int, c_int_p, c_int_p, c_float_p, c_float_p]
         L.orc_set_exact.argtypes = [ctypes.c_int]
+        pp = ctypes.POINTER(c_float_p)
+        L.orc_forward_batch.restype = ctypes.c_int
+        L.orc_forward_batch.argtypes = [ctypes.POINTER(_Stack), pp, pp, c_int_p, c_int_p, ctypes.c_int, c_float_p, c_float_p]
+        L.orc_cp_predict_batch.restype = ctypes.c_int
+        L.orc_cp_predict_batch.argtypes = [ctypes.POINTER(_Stack), c_float_p, ctypes.c_int, pp, pp, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, c_float_p, c_int_p, c_int_p, c_int_p, c_float_p]
+        L.orc_head_batch.argtypes = [c_float_p, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_int, c_float_p]
         L.orc_matvec.argtypes = [c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int]
-        L.orc_rmsnorm_round.argtypes = [c_float_p, c_float_p, ctypes.c_float, ctypes.c_int, c_float_p]
+        L.orc_rmsnorm_fold.restype = ctypes.c_float
+        L.orc_rmsnorm_fold.argtypes = [c_float_p, c_float_p, ctypes.c_float, ctypes.c_int, c_float_p]
         _LIB = L
     return _LIB
 
@@ -171,6 +179,31 @@ class TalkerOracle(StackOracle):
         return head_logits(self.codec_head, hidden)
 
 
+def forward_batch(stack: StackOracle, caches, pos, embd: np.ndarray) -> np.ndarray:
+    """One decode step of B independent sequences through `stack`'s weights: caches = [(kc, vc, n_ctx)] per row
+    (arrays shaped like StackOracle.kc), pos[b] = position appended.  Per row identical to StackOracle.forward."""
+    B = len(caches)
+    embd = _f32(embd).reshape(B, stack.cfg.hidden)
+    kcp = (c_float_p * B)(*[fp(c[0]) for c in caches])
+    vcp = (c_float_p * B)(*[fp(c[1]) for c in caches])
+    nctx = np.ascontiguousarray([c[2] for c in caches], dtype=np.int32)
+    posa = np.ascontiguousarray(pos, dtype=np.int32)
+    out = np.empty((B, stack.cfg.hidden), np.float32)
+    rc = lib().orc_forward_batch(ctypes.byref(stack.st), kcp, vcp, nctx.ctypes.data_as(c_int_p),
+                                 posa.ctypes.data_as(c_int_p), B, fp(embd), fp(out))
+    if rc != 0:
+        raise RuntimeError("orc_forward_batch failed (context overflow?)")
+    return out
+
+
+def head_logits_batch(head_f32: np.ndarray, hidden: np.ndarray) -> np.ndarray:
+    V, H = head_f32.shape
+    hidden = _f32(hidden).reshape(-1, H)
+    out = np.empty((hidden.shape[0], V), np.float32)
+    lib().orc_head_batch(fp(head_f32), V, H, fp(hidden), hidden.shape[0], fp(out))
+    return out
+
+
 class CpOracle(StackOracle):
     def __init__(self, cfg, tensors):
         super().__init__(cfg, tensors, "cp", cfg.cp_layers, cfg.cp_ffn, cfg.cp_groups + 1)
@@ -197,3 +230,20 @@ class CpOracle(StackOracle):
         if rc != 0:
             raise RuntimeError("orc_cp_predict failed")
         return (codes, margins, hid) if want_hidden else (codes, margins)
+
+    def predict_batch(self, hidden, code0, forced=None):
+        """B rows at once -> (codes[B][15], margins[B][15]); per row identical to predict()."""
+        G, H = self.cfg.cp_groups, self.cfg.hidden
+        hidden = _f32(hidden).reshape(-1, H)
+        B = hidden.shape[0]
+        c0 = np.ascontiguousarray(code0, dtype=np.int32).reshape(B)
+        codes = np.zeros((B, G), np.int32)
+        margins = np.zeros((B, G), np.float32)
+        f = None if forced is None else np.ascontiguousarray(forced, dtype=np.int32).reshape(B, G)
+        rc = lib().orc_cp_predict_batch(ctypes.byref(self.st), fp(self.talker_emb), self.talker_emb.shape[0],
+                                        self._emb_p, self._head_p, self.cfg.cp_vocab, G, B, fp(hidden),
+                                        c0.ctypes.data_as(c_int_p), f.ctypes.data_as(c_int_p) if f is not None else None,
+                                        codes.ctypes.data_as(c_int_p), fp(margins))
+        if rc != 0:
+            raise RuntimeError("orc_cp_predict_batch failed")
+        return codes, margins

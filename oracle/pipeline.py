@@ -50,3 +50,57 @@ class CpuPipeline:
             hidden = self.talker.forward(fb, pos)
             pos += 1
         return (frames, margins_all) if want_margins else frames
+
+
+    def generate_batch(self, prefixes, n_text, pad_embed, max_frames, ignore_eos=False):
+        """The same loop for B utterances in lock step, weights read once per pass for the whole batch: per
+        utterance bit-identical to generate() (rows never mix; checked in tests/test_weights_container.py).
+        -> (frames[b] list of 16-int lists, margins[b] list of 16 gaps) per utterance."""
+        cfg = self.cfg
+        B = len(prefixes)
+        caches, hid, pos = [], [], []
+        for p in prefixes:
+            self.talker.clear()
+            hid.append(self.talker.forward(p, 0))
+            caches.append((self.talker.kc, self.talker.vc, self.talker.n_ctx))
+            pos.append(p.shape[0])
+        hid = np.stack(hid)
+        past = [[] for _ in range(B)]
+        frames = [[] for _ in range(B)]
+        margins = [[] for _ in range(B)]
+        alive = list(range(B))
+        for _ in range(max_frames):
+            if not alive:
+                break
+            logits = orc.head_logits_batch(self.talker.codec_head, hid[alive])
+            code0, keep = [], []
+            for j, b in enumerate(alive):
+                lg, forced = fe.process_talker_logits(logits[j], past[b], n_text[b], cfg.codec_eos)
+                if ignore_eos:
+                    lg[cfg.codec_eos] = -1e10
+                    c0 = int(np.argmax(lg))
+                else:
+                    c0 = int(forced) if forced is not None else int(np.argmax(lg))
+                srt = np.sort(lg)
+                m0 = float(srt[-1] - srt[-2])
+                if c0 == cfg.codec_eos or c0 >= 2048:
+                    margins[b].append([m0] + [np.inf] * 15)
+                    continue
+                margins[b].append([m0])
+                code0.append(c0)
+                keep.append(b)
+            alive = keep
+            if not alive:
+                break
+            codes, cm = self.cp.predict_batch(hid[alive], code0)
+            fb = []
+            for j, b in enumerate(alive):
+                margins[b][-1] += [float(x) for x in cm[j]]
+                frames[b].append([code0[j]] + [int(c) for c in codes[j]])
+                past[b].append(code0[j])
+                fb.append(fe.feedback_embedding(code0[j], codes[j], self.codec_embedding, self.cp_emb, pad_embed))
+            hid[alive] = orc.forward_batch(self.talker, [caches[b] for b in alive], [pos[b] for b in alive], np.stack(fb))
+            for b in alive:
+                pos[b] += 1
+        self.last_hidden = hid      # talker hidden of every utterance after its last executed step
+        return frames, margins

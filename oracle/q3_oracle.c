@@ -19,7 +19,10 @@
  *
  * Numerics contract (same as the HIP kernels, DESIGN.md "Numerics"): projection weights are
  * fp16 values (passed here already widened to f32), every GEMM input is rounded to fp16
- * (saturating), accumulation and everything else is f32; K/V are stored rounded to fp16.
+ * (saturating), accumulation and everything else is f32; K/V are stored rounded to fp16; RMSNorm is
+ * folded around the GEMM it feeds (input fp16((h*gamma)/16), results times 16*inv_rms).
+ * What pins it: tests/test_oracle_vs_hf.py compares this file with transformers' Qwen3Model (fp32) on
+ * seeded weights -- 1e-6 in exact mode, 1e-3 under the rounding contract.
  */
 #include <math.h>
 #include <stdint.h>
@@ -103,22 +106,41 @@ void orc_rope_tables(double theta, int head_dim, int max_pos, float* cs, float* 
     }
 }
 
-/* y[n] = sum_k W[n][k] x[k], f32 accumulate */
-static void matvec(const float* W, const float* x, float* y, int N, int K) {
+/* Dot product in f32 with eight interleaved partial sums (lane j takes k = j mod 8), combined pairwise at the
+ * end: a fixed order the compiler can keep in one 8-wide register.  K is a multiple of 8 everywhere here. */
+static inline float dot8(const float* w, const float* x, int K) {
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; k += 8)
+        for (int j = 0; j < 8; j++) a[j] += w[k + j] * x[k + j];
+    return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
+/* Y[t][n] = sum_k W[n][k] X[t][k] for T rows (ldx / ldy = row strides), f32 accumulate.  Weight rows are walked
+ * once and reused for every token of a block while they sit in cache. */
+static void matmul_rows(const float* W, const float* X, int ldx, float* Y, int ldy, int T, int N, int K) {
 #pragma omp parallel for schedule(static)
     for (int n = 0; n < N; n++) {
         const float* w = W + (size_t)n * K;
-        float acc = 0.f;
-        for (int k = 0; k < K; k++) acc += w[k] * x[k];
-        y[n] = acc;
+        for (int t = 0; t < T; t++) Y[(size_t)t * ldy + n] = dot8(w, X + (size_t)t * ldx, K);
     }
 }
+static void matvec(const float* W, const float* x, float* y, int N, int K) { matmul_rows(W, x, K, y, N, 1, N, K); }
 
-static void rmsnorm_round(const float* h, const float* gamma, float eps, int H, float* x16) {
+/* RMSNorm folded around the GEMM (the device's numerics contract): the GEMM input is
+ * x16 = fp16((h * gamma) / 16) -- the norm weight applied, a fixed power-of-two pre-scale -- and the GEMM's f32
+ * results are multiplied by the returned inv_rms * 16.  In exact mode (no rounding) this IS RMSNorm followed by
+ * the projection, up to f32 round-off. */
+#define NORM_PRE 0.0625f
+#define NORM_POST 16.0f
+static float rmsnorm_fold(const float* h, const float* gamma, float eps, int H, float* x16) {
     double ss = 0.0;
     for (int k = 0; k < H; k++) ss += (double)h[k] * h[k];
-    const float inv = 1.0f / sqrtf((float)ss / (float)H + eps);
-    for (int k = 0; k < H; k++) x16[k] = act_round((h[k] * inv) * gamma[k]);
+    for (int k = 0; k < H; k++) x16[k] = act_round((h[k] * gamma[k]) * NORM_PRE);
+    return (1.0f / sqrtf((float)ss / (float)H + eps)) * NORM_POST;
+}
+static void scale_rows(float* Y, int ld, int T, int N, const float* post) {
+    for (int t = 0; t < T; t++)
+        for (int n = 0; n < N; n++) Y[(size_t)t * ld + n] *= post[t];
 }
 
 static void head_norm_rope(float* x, const float* gamma, float eps, int D, const float* cs, const float* sn) {
@@ -134,76 +156,119 @@ static void head_norm_rope(float* x, const float* gamma, float eps, int D, const
     }
 }
 
-/* One token through every layer.  kc/vc: [n_layers][n_kv][n_ctx][D] holding fp16-rounded values.
- * h (in/out): residual stream [H]. */
-static void token_forward(const orc_stack* st, float* kc, float* vc, int n_ctx, int pos, float* h, float* scratch) {
+/* One row of a layer-major pass: the cache it appends to / attends over, and its position there. */
+typedef struct {
+    float *kc, *vc; /* [n_layers][n_kv][n_ctx][D] holding fp16-rounded values */
+    int n_ctx, pos;
+} orc_row;
+
+/* T rows through every layer, layer by layer (each row's arithmetic is the same as walking it alone; only the
+ * loop order differs, so weights are read once per layer for all rows).  Rows may belong to one sequence
+ * (prefill: consecutive positions of one cache; a row attends to the rows before it, whose K/V of this layer are
+ * appended first) or to different sequences (a batch of decode steps, every row with its own cache).
+ * h (in/out): residual streams [T][H]. */
+static int rows_forward(const orc_stack* st, const orc_row* rows, int T, float* h) {
     const int H = st->hidden, D = st->head_dim, NH = st->n_heads, NKV = st->n_kv, F = st->ffn;
-    const int rep = NH / NKV;
-    float* x16 = scratch;                 /* H */
-    float* q = x16 + H;                   /* NH*D */
-    float* kn = q + NH * D;               /* NKV*D */
-    float* vn = kn + NKV * D;             /* NKV*D */
-    float* att = vn + NKV * D;            /* NH*D */
-    float* g = att + NH * D;              /* F */
-    float* u = g + F;                     /* F */
-    float* y = u + F;                     /* H */
-    float* sc = y + H;                    /* n_ctx */
+    const int rep = NH / NKV, QD = NH * D, KD = NKV * D;
+    const size_t per_tok = (size_t)H + QD + 2 * KD + QD + 2 * (size_t)F + H;
+    float* buf = (float*)malloc(sizeof(float) * (per_tok * T));
+    if (!buf) return -1;
+    float* x16 = buf;                        /* [T][H]  */
+    float* q = x16 + (size_t)T * H;          /* [T][QD] */
+    float* kn = q + (size_t)T * QD;          /* [T][KD] */
+    float* vn = kn + (size_t)T * KD;         /* [T][KD] */
+    float* att = vn + (size_t)T * KD;        /* [T][QD] */
+    float* g = att + (size_t)T * QD;         /* [T][F]  */
+    float* u = g + (size_t)T * F;            /* [T][F]  */
+    float* y = u + (size_t)T * F;            /* [T][H]  */
+    float* post = (float*)malloc(sizeof(float) * T);
+    if (!post) return -1;
     const float scale = 1.0f / sqrtf((float)D);
-    const float* cs = st->rope_cos + (size_t)pos * (D / 2);
-    const float* sn = st->rope_sin + (size_t)pos * (D / 2);
     for (int l = 0; l < st->n_layers; l++) {
         const orc_layer* L = &st->layers[l];
-        rmsnorm_round(h, L->in_ln, st->eps, H, x16);
-        matvec(L->q, x16, q, NH * D, H);
-        matvec(L->k, x16, kn, NKV * D, H);
-        matvec(L->v, x16, vn, NKV * D, H);
-        for (int hd = 0; hd < NH; hd++) head_norm_rope(q + hd * D, L->q_norm, st->eps, D, cs, sn);
-        float* kl = kc + (size_t)l * NKV * n_ctx * D;
-        float* vl = vc + (size_t)l * NKV * n_ctx * D;
-        for (int gk = 0; gk < NKV; gk++) {
-            head_norm_rope(kn + gk * D, L->k_norm, st->eps, D, cs, sn);
-            for (int i = 0; i < D; i++) {
-                kl[((size_t)gk * n_ctx + pos) * D + i] = act_round(kn[gk * D + i]);
-                vl[((size_t)gk * n_ctx + pos) * D + i] = act_round(vn[gk * D + i]);
+        for (int t = 0; t < T; t++) post[t] = rmsnorm_fold(h + (size_t)t * H, L->in_ln, st->eps, H, x16 + (size_t)t * H);
+        matmul_rows(L->q, x16, H, q, QD, T, QD, H);
+        matmul_rows(L->k, x16, H, kn, KD, T, KD, H);
+        matmul_rows(L->v, x16, H, vn, KD, T, KD, H);
+        scale_rows(q, QD, T, QD, post);
+        scale_rows(kn, KD, T, KD, post);
+        scale_rows(vn, KD, T, KD, post);
+        for (int t = 0; t < T; t++) {
+            const int pos = rows[t].pos, n_ctx = rows[t].n_ctx;
+            float* kl = rows[t].kc + (size_t)l * NKV * n_ctx * D;
+            float* vl = rows[t].vc + (size_t)l * NKV * n_ctx * D;
+            const float* cs = st->rope_cos + (size_t)pos * (D / 2);
+            const float* sn = st->rope_sin + (size_t)pos * (D / 2);
+            for (int hd = 0; hd < NH; hd++) head_norm_rope(q + (size_t)t * QD + hd * D, L->q_norm, st->eps, D, cs, sn);
+            for (int gk = 0; gk < NKV; gk++) {
+                float* kt = kn + (size_t)t * KD + gk * D;
+                head_norm_rope(kt, L->k_norm, st->eps, D, cs, sn);
+                for (int i = 0; i < D; i++) {
+                    kl[((size_t)gk * n_ctx + pos) * D + i] = act_round(kt[i]);
+                    vl[((size_t)gk * n_ctx + pos) * D + i] = act_round(vn[(size_t)t * KD + gk * D + i]);
+                }
             }
         }
-        for (int hd = 0; hd < NH; hd++) {
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int th = 0; th < T * NH; th++) {
+            const int t = th / NH, hd = th % NH, pos = rows[t].pos, n_ctx = rows[t].n_ctx;
             const int gk = hd / rep;
-            const float* qh = q + hd * D;
+            const float* kl = rows[t].kc + (size_t)l * NKV * n_ctx * D;
+            const float* vl = rows[t].vc + (size_t)l * NKV * n_ctx * D;
+            const float* qh = q + (size_t)t * QD + hd * D;
+            float* sc = (float*)malloc(sizeof(float) * (pos + 1));
             float mx = -INFINITY;
-            for (int t = 0; t <= pos; t++) {
-                const float* kr = kl + ((size_t)gk * n_ctx + t) * D;
-                float d = 0.f;
-                for (int i = 0; i < D; i++) d += qh[i] * kr[i];
-                sc[t] = d * scale;
-                if (sc[t] > mx) mx = sc[t];
+            for (int tt = 0; tt <= pos; tt++) {
+                sc[tt] = dot8(qh, kl + ((size_t)gk * n_ctx + tt) * D, D) * scale;
+                if (sc[tt] > mx) mx = sc[tt];
             }
             float sum = 0.f;
-            for (int t = 0; t <= pos; t++) {
-                sc[t] = expf(sc[t] - mx);
-                sum += sc[t];
+            for (int tt = 0; tt <= pos; tt++) {
+                sc[tt] = expf(sc[tt] - mx);
+                sum += sc[tt];
             }
-            float* oh = att + hd * D;
+            float* oh = att + (size_t)t * QD + hd * D;
             for (int i = 0; i < D; i++) oh[i] = 0.f;
-            for (int t = 0; t <= pos; t++) {
-                const float* vr = vl + ((size_t)gk * n_ctx + t) * D;
-                const float p = sc[t];
+            for (int tt = 0; tt <= pos; tt++) {
+                const float* vr = vl + ((size_t)gk * n_ctx + tt) * D;
+                const float p = sc[tt];
                 for (int i = 0; i < D; i++) oh[i] += p * vr[i];
             }
             for (int i = 0; i < D; i++) oh[i] = act_round(oh[i] / sum);
+            free(sc);
         }
-        matvec(L->o, att, y, H, NH * D);
-        for (int k = 0; k < H; k++) h[k] += y[k];
-        rmsnorm_round(h, L->post_ln, st->eps, H, x16);
-        matvec(L->gate, x16, g, F, H);
-        matvec(L->up, x16, u, F, H);
-        for (int j = 0; j < F; j++) {
+        matmul_rows(L->o, att, QD, y, H, T, H, QD);
+        for (size_t i = 0; i < (size_t)T * H; i++) h[i] += y[i];
+        for (int t = 0; t < T; t++) post[t] = rmsnorm_fold(h + (size_t)t * H, L->post_ln, st->eps, H, x16 + (size_t)t * H);
+        matmul_rows(L->gate, x16, H, g, F, T, F, H);
+        matmul_rows(L->up, x16, H, u, F, T, F, H);
+        scale_rows(g, F, T, F, post);
+        scale_rows(u, F, T, F, post);
+        for (size_t j = 0; j < (size_t)T * F; j++) {
             const float sg = g[j] / (1.0f + expf(-g[j]));
             g[j] = act_round(sg * u[j]);
         }
-        matvec(L->down, g, y, H, F);
-        for (int k = 0; k < H; k++) h[k] += y[k];
+        matmul_rows(L->down, g, F, y, H, T, H, F);
+        for (size_t i = 0; i < (size_t)T * H; i++) h[i] += y[i];
     }
+    free(buf);
+    free(post);
+    return 0;
+}
+
+/* T consecutive tokens of one sequence (positions pos0 .. pos0+T-1) */
+static int tokens_forward(const orc_stack* st, float* kc, float* vc, int n_ctx, int pos0, int T, float* h) {
+    orc_row* rows = (orc_row*)malloc(sizeof(orc_row) * T);
+    if (!rows) return -1;
+    for (int t = 0; t < T; t++) rows[t] = (orc_row){kc, vc, n_ctx, pos0 + t};
+    const int rc = rows_forward(st, rows, T, h);
+    free(rows);
+    return rc;
+}
+
+static void token_forward(const orc_stack* st, float* kc, float* vc, int n_ctx, int pos, float* h, float* scratch) {
+    (void)scratch;
+    tokens_forward(st, kc, vc, n_ctx, pos, 1, h);
 }
 
 static size_t scratch_floats(const orc_stack* st, int n_ctx) {
@@ -224,17 +289,18 @@ static void final_norm(const orc_stack* st, const float* h, float* out) {
 int orc_forward(const orc_stack* st, float* kc, float* vc, int n_ctx, const float* embd, int n_tokens, int pos_start,
                 float* out_last, float* out_all) {
     if (pos_start < 0 || pos_start + n_tokens > n_ctx) return -1;
-    const int H = st->hidden;
-    float* scratch = (float*)malloc(sizeof(float) * scratch_floats(st, n_ctx));
-    float* h = (float*)malloc(sizeof(float) * H);
-    if (!scratch || !h) return -1;
-    for (int t = 0; t < n_tokens; t++) {
-        memcpy(h, embd + (size_t)t * H, sizeof(float) * H);
-        token_forward(st, kc, vc, n_ctx, pos_start + t, h, scratch);
-        if (out_all) final_norm(st, h, out_all + (size_t)t * H);
-        if (t == n_tokens - 1 && out_last) final_norm(st, h, out_last);
+    const int H = st->hidden, BLK = 64;
+    float* h = (float*)malloc(sizeof(float) * (size_t)H * (n_tokens < BLK ? n_tokens : BLK));
+    if (!h) return -1;
+    for (int t0 = 0; t0 < n_tokens; t0 += BLK) {
+        const int T = n_tokens - t0 < BLK ? n_tokens - t0 : BLK;
+        memcpy(h, embd + (size_t)t0 * H, sizeof(float) * (size_t)T * H);
+        if (tokens_forward(st, kc, vc, n_ctx, pos_start + t0, T, h)) return -1;
+        for (int t = 0; t < T; t++) {
+            if (out_all) final_norm(st, h + (size_t)t * H, out_all + (size_t)(t0 + t) * H);
+            if (t0 + t == n_tokens - 1 && out_last) final_norm(st, h + (size_t)t * H, out_last);
+        }
     }
-    free(scratch);
     free(h);
     return 0;
 }
@@ -284,7 +350,11 @@ int orc_cp_predict(const orc_stack* cp, const float* talker_emb, int talker_voca
         token_forward(cp, kc, vc, n_ctx, g + 1, h, scratch);
         final_norm(cp, h, hid);
         if (out_hidden_all) memcpy(out_hidden_all + (size_t)g * H, hid, sizeof(float) * H);
-        orc_head(cp_head[g], cp_vocab, H, hid, logits);
+        {   /* the group head is a GEMM over the final-normed state: folded like every normed GEMM */
+            const float post = rmsnorm_fold(h, cp->final_norm, cp->eps, H, hid);
+            matvec(cp_head[g], hid, logits, cp_vocab, H);
+            for (int v = 0; v < cp_vocab; v++) logits[v] *= post;
+        }
         int tok = argmax_lowest(logits, cp_vocab, margins ? &margins[g] : NULL);
         out_codes[g] = tok;
         if (forced && forced[g] >= 0) tok = forced[g];
@@ -297,8 +367,78 @@ int orc_cp_predict(const orc_stack* cp, const float* talker_emb, int talker_voca
     return 0;
 }
 
+/* One decode step of B independent sequences (row b: cache kc[b]/vc[b] of n_ctx[b] positions, appended at pos[b]):
+ * the batched form of orc_forward(n_tokens = 1); per row bit-identical to it.  out: post-final-norm hidden [B][H]. */
+int orc_forward_batch(const orc_stack* st, float* const* kc, float* const* vc, const int* n_ctx, const int* pos, int B,
+                      const float* embd, float* out) {
+    const int H = st->hidden;
+    orc_row* rows = (orc_row*)malloc(sizeof(orc_row) * B);
+    float* h = (float*)malloc(sizeof(float) * (size_t)B * H);
+    if (!rows || !h) return -1;
+    for (int b = 0; b < B; b++) {
+        if (pos[b] < 0 || pos[b] >= n_ctx[b]) return -1;
+        rows[b] = (orc_row){kc[b], vc[b], n_ctx[b], pos[b]};
+    }
+    memcpy(h, embd, sizeof(float) * (size_t)B * H);
+    if (rows_forward(st, rows, B, h)) return -1;
+    for (int b = 0; b < B; b++) final_norm(st, h + (size_t)b * H, out + (size_t)b * H);
+    free(rows);
+    free(h);
+    return 0;
+}
+
+/* orc_cp_predict for B rows at once (weights read once per pass for the whole batch); per row bit-identical to
+ * it.  hidden [B][H], code0 [B], forced [B][n_groups] or NULL, out_codes / margins [B][n_groups]. */
+int orc_cp_predict_batch(const orc_stack* cp, const float* talker_emb, int talker_vocab, const float* const* cp_emb,
+                         const float* const* cp_head, int cp_vocab, int n_groups, int B, const float* hidden,
+                         const int* code0, const int* forced, int* out_codes, float* margins) {
+    const int H = cp->hidden, D = cp->head_dim, n_ctx = n_groups + 1;
+    const size_t kvn = (size_t)cp->n_layers * cp->n_kv * n_ctx * D;
+    float* kc = (float*)calloc(kvn * B, sizeof(float));
+    float* vc = (float*)calloc(kvn * B, sizeof(float));
+    orc_row* rows = (orc_row*)malloc(sizeof(orc_row) * B);
+    float* h = (float*)malloc(sizeof(float) * (size_t)B * H);
+    float* x = (float*)malloc(sizeof(float) * (size_t)B * H);
+    float* logits = (float*)malloc(sizeof(float) * (size_t)B * cp_vocab);
+    float* rows_post = (float*)malloc(sizeof(float) * B);
+    if (!kc || !vc || !rows || !h || !x || !logits || !rows_post) return -1;
+    for (int b = 0; b < B; b++) rows[b] = (orc_row){kc + kvn * b, vc + kvn * b, n_ctx, 0};
+    memcpy(h, hidden, sizeof(float) * (size_t)B * H);
+    if (rows_forward(cp, rows, B, h)) return -1;
+    for (int b = 0; b < B; b++) {
+        if (code0[b] >= 0 && code0[b] < talker_vocab) memcpy(h + (size_t)b * H, talker_emb + (size_t)code0[b] * H, sizeof(float) * H);
+        else memset(h + (size_t)b * H, 0, sizeof(float) * H);
+    }
+    for (int g = 0; g < n_groups; g++) {
+        for (int b = 0; b < B; b++) rows[b].pos = g + 1;
+        if (rows_forward(cp, rows, B, h)) return -1;
+        for (int b = 0; b < B; b++) rows_post[b] = rmsnorm_fold(h + (size_t)b * H, cp->final_norm, cp->eps, H, x + (size_t)b * H);
+        matmul_rows(cp_head[g], x, H, logits, cp_vocab, B, cp_vocab, H);
+        scale_rows(logits, cp_vocab, B, cp_vocab, rows_post);
+        for (int b = 0; b < B; b++) {
+            int tok = argmax_lowest(logits + (size_t)b * cp_vocab, cp_vocab, margins ? &margins[(size_t)b * n_groups + g] : NULL);
+            out_codes[(size_t)b * n_groups + g] = tok;
+            if (forced && forced[(size_t)b * n_groups + g] >= 0) tok = forced[(size_t)b * n_groups + g];
+            if (g + 1 < n_groups) {
+                if (tok >= 0 && tok < cp_vocab) memcpy(h + (size_t)b * H, cp_emb[g] + (size_t)tok * H, sizeof(float) * H);
+                else memset(h + (size_t)b * H, 0, sizeof(float) * H);
+            }
+        }
+    }
+    free(kc); free(vc); free(rows); free(h); free(x); free(logits); free(rows_post);
+    return 0;
+}
+
+/* logits[B][V] = head . fp16(hidden[b])  (batched orc_head) */
+void orc_head_batch(const float* head, int V, int H, const float* hidden, int B, float* logits) {
+    float* x = (float*)malloc(sizeof(float) * (size_t)B * H);
+    for (size_t i = 0; i < (size_t)B * H; i++) x[i] = act_round(hidden[i]);
+    matmul_rows(head, x, H, logits, V, B, V, H);
+    free(x);
+}
+
 /* Plain linear pieces for kernel-level checks: y = W . fp16round(x) etc. */
 void orc_matvec(const float* W, const float* x, float* y, int N, int K) { matvec(W, x, y, N, K); }
-void orc_rmsnorm_round(const float* h, const float* gamma, float eps, int H, float* x16) {
-    rmsnorm_round(h, gamma, eps, H, x16);
+float orc_rmsnorm_fold(const float* h, const float* gamma, float eps, int H, float* x16) {
+    return rmsnorm_fold(h, gamma, eps, H, x16);
 }

@@ -11,6 +11,8 @@ struct CpFrameIO {
     // feedback after the last group (tts_client.py:199-208); null = none
     float* fb_h = nullptr;
     float* fb_ssq = nullptr;
+    half_t* fb_xh = nullptr;          // pre-scaled GEMM input of the talker's first layer ...
+    const float* fb_gamma = nullptr;  // ... and that layer's input norm weight
     const float* pad_embed = nullptr;
     // sampling of the 15 groups (code_predictor_server.py:87-92): temperature <= 1e-6 = arg-max
     float temperature = 0.f;

@@ -19,7 +19,7 @@ int cp_frame(hipStream_t s, const Model& m, Work& w, KVCache& kv, int R, const C
     if (run_stack(s, m, m.cp, w, kv, R, rm, 256, row0)) return -1;
     // position 1: TALKER codec embedding of code_0 (:97-98,123-124)
     if (launch_gather_embed(s, m.talker_emb, c.talker_vocab, H, io.codes, 0, io.n_frames, io.frame_cap, 0, w.h, w.ssq, R,
-                            row0, R_total, io.forced))
+                            row0, R_total, io.forced, w.xh, m.cp.L[0].in_ln))
         return -1;
     for (int g = 0; g < G; g++) {
         rm.pos_base = g + 1;
@@ -32,10 +32,9 @@ int cp_frame(hipStream_t s, const Model& m, Work& w, KVCache& kv, int R, const C
         a.M = row0 + R;
         a.m_begin = row0;
         a.nt = 0;
-        a.h = w.h;
+        a.x16 = w.xh;          // fp16((h * final_norm) / 16) from the last layer's down projection
         a.ssq = w.ssq;
         a.ssq_parts = H / 16;
-        a.gamma = m.cp.final_norm;
         a.eps = c.eps;
         a.y = w.logits;
         a.ldy = c.cp_vocab;
@@ -60,6 +59,8 @@ int cp_frame(hipStream_t s, const Model& m, Work& w, KVCache& kv, int R, const C
             x.next_table = m.cp_emb[g];  // group g+1 embeds token g with CP table g (:134)
             x.h_out = w.h;
             x.ssq_out = w.ssq;
+            x.xh_out = w.xh;
+            x.gamma_next = m.cp.L[0].in_ln;
         } else if (io.fb_h) {
             x.talker_emb = m.talker_emb;
             x.talker_vocab = c.talker_vocab;
@@ -68,6 +69,8 @@ int cp_frame(hipStream_t s, const Model& m, Work& w, KVCache& kv, int R, const C
             x.n_groups = G;
             x.h_out = io.fb_h;
             x.ssq_out = io.fb_ssq;
+            x.xh_out = io.fb_xh;
+            x.gamma_next = io.fb_gamma;
         }
         if (launch_cp_argmax(s, x)) return -1;
     }
@@ -166,7 +169,7 @@ int cp_predict_batch(void* hh, const float* hidden, const int32_t* code_0, int n
     io.top_k = top_k;
     io.seed = seed;
     auto body = [&]() -> int {
-        if (launch_ssq_rows(h->s, h->w.rows_in, h->w.h, h->w.ssq, R, H)) return -1;
+        if (launch_ssq_rows(h->s, h->w.rows_in, h->w.h, h->w.ssq, R, H, h->w.xh, m.cp.L[0].in_ln)) return -1;
         return cp_frame(h->s, m, h->w, h->kv, R, io);
     };
     if (stochastic) {
@@ -207,7 +210,7 @@ int cp_step(void* hh, const float* embed, int position, float* out_hidden) {
     const int H = m.cfg.hidden;
     if (position < 0 || position > m.cfg.cp_groups) return -1;
     Q3_HIP(hipMemcpyAsync(h->w.rows_in, embed, sizeof(float) * H, hipMemcpyHostToDevice, h->s), -1);
-    if (launch_ssq_rows(h->s, h->w.rows_in, h->w.h, h->w.ssq, 1, H)) return -1;
+    if (launch_ssq_rows(h->s, h->w.rows_in, h->w.h, h->w.ssq, 1, H, h->w.xh, m.cp.L[0].in_ln)) return -1;
     RowMap rm;
     rm.pos_base = position;
     if (run_stack(h->s, m, m.cp, h->w, h->kv, 1, rm, 256)) return -1;

@@ -65,6 +65,8 @@ int talker_tail(Engine* e, hipStream_t st, int row0, int R) {
     f.out_f16 = e->wt.hidden_f16;
     f.out_copy = e->wc.h;
     f.out_copy_ssq = e->wc.ssq;
+    f.out_copy_xh = e->wc.xh;
+    f.out_copy_gamma = m.cp.L[0].in_ln;
     if (launch_final_norm(st, f)) return -1;
     LinArgs a;
     a.wp = m.talker_head.wp;
@@ -113,6 +115,8 @@ int frame_chain(Engine* e, hipStream_t st, int row0, int R) {
     io.frame_cap = e->max_frames;
     io.fb_h = e->wt.h;
     io.fb_ssq = e->wt.ssq;
+    io.fb_xh = e->wt.xh;
+    io.fb_gamma = m.talker.L[0].in_ln;
     io.pad_embed = e->d_pad;
     io.temperature = e->c_temp;
     io.top_k = e->c_top_k;
@@ -370,7 +374,7 @@ int q3e_start(void* ee, int B, const float* prefix, const int32_t* n_rows, const
         Q3_HIP(hipMemcpyAsync(e->d_slot, slot.data(), sizeof(int) * rows, hipMemcpyHostToDevice, e->s), -1);
         Q3_HIP(hipMemcpyAsync(e->d_pos, pos.data(), sizeof(int) * rows, hipMemcpyHostToDevice, e->s), -1);
         Q3_HIP(hipMemcpyAsync(e->d_lastrow + b0, last.data() + b0, sizeof(int) * (b1 - b0), hipMemcpyHostToDevice, e->s), -1);
-        if (launch_ssq_rows(e->s, e->wt.rows_in, e->wt.h, e->wt.ssq, rows, H)) return -1;
+        if (launch_ssq_rows(e->s, e->wt.rows_in, e->wt.h, e->wt.ssq, rows, H, e->wt.xh, m.talker.L[0].in_ln)) return -1;
         RowMap rm;
         rm.slot = e->d_slot;
         rm.pos = e->d_pos;
@@ -392,6 +396,8 @@ int q3e_start(void* ee, int B, const float* prefix, const int32_t* n_rows, const
             f.out_f16 = e->wt.hidden_f16;
             f.out_copy = e->wc.h;
             f.out_copy_ssq = e->wc.ssq;
+            f.out_copy_xh = e->wc.xh;
+            f.out_copy_gamma = m.cp.L[0].in_ln;
             if (launch_final_norm(e->s, f)) return -1;
         }
         Q3_HIP(hipStreamSynchronize(e->s), -1);  // host staging vectors are reused by the next group

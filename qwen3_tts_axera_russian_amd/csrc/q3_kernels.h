@@ -3,6 +3,8 @@
 // Numerics contract shared with oracle/q3_oracle.c (DESIGN.md "Numerics"):
 //   * projection weights fp16, residual stream / norms / softmax / tables f32,
 //     every GEMM input rounded to fp16 (saturating), f32 accumulation;
+//   * RMSNorm folded around the GEMM: input xh = fp16((h*gamma)/16) written by the producer of h,
+//     accumulators multiplied by inv_rms(row)*16;
 //   * K/V cache fp16, q kept f32.
 #pragma once
 #include "q3_common.h"
@@ -21,20 +23,21 @@ struct LinArgs {
     int swap_grid = 0;  // set by the launcher
     int nt = 0;  // 1: stream the weights with non-temporal loads (read once per step: talker)
     // A operands are stored in MFMA fragment order (frag_idx), buffers padded to 16 rows.
-    // prologue PRO_F16: A = x16[M][K] (fp16).  PRO_NORM: A = fp16((h*inv)*gamma),
-    // inv[m] = 1/sqrt(sum(ssq[m][0..ssq_parts))/K + eps).
+    // prologue PRO_F16: A = x16[M][K] (fp16).  PRO_NORM: A = x16 = the producer's xh = fp16((h*gamma)/16) and the
+    // accumulators are multiplied by 16*inv[m], inv[m] = 1/sqrt(sum(ssq[m][0..ssq_parts))/K + eps).
     const half_t* x16 = nullptr;
-    const float* h = nullptr;
     const float* ssq = nullptr;
     int ssq_parts = 0;
-    const float* gamma = nullptr;
     float eps = 1e-6f;
     // EPI_STORE: y[m*ldy + n] = acc
     float* y = nullptr;
     int ldy = 0;
-    // EPI_RESID: h_out[m*N+n] += acc; ssq_out[m*(N/16) + n/16] = sum of squares of the new 16 values
+    // EPI_RESID: h_out[m*N+n] += acc; ssq_out[m*(N/16) + n/16] = sum of squares of the new 16 values;
+    // xh_out[m][n] = fp16((h_out*gamma[n])/16) for the consumer whose norm weight is `gamma` (null: none)
     float* h_out = nullptr;
     float* ssq_out = nullptr;
+    half_t* xh_out = nullptr;
+    const float* gamma = nullptr;
     // EPI_SWIGLU (gate/up tile-interleaved weights): act[m*(N/2)+j] = fp16(silu(g)*u)
     half_t* act = nullptr;
 };
@@ -69,7 +72,9 @@ int launch_attn(hipStream_t s, const AttnArgs& a, int mode);
 
 // Uploaded row-major rows[R][H] -> residual stream h in fragment order (see frag_idx in q3_kernels.hip)
 // + ssq[m][p] = sum_{k in 16-block p} rows[m][k]^2  (H/16 partials per row)
-int launch_ssq_rows(hipStream_t s, const float* rows, float* h, float* ssq, int R, int H);
+// + xh = fp16((rows*gamma)/16), the pre-scaled GEMM input of the layer whose norm weight is gamma (null: none)
+int launch_ssq_rows(hipStream_t s, const float* rows, float* h, float* ssq, int R, int H, half_t* xh = nullptr,
+                    const float* gamma = nullptr);
 
 // hidden = (h*inv)*gamma per row; optional outputs: f32 hidden, fp16 hidden,
 // a second f32 copy (+ its ssq partials) that seeds the code predictor.
@@ -87,6 +92,8 @@ struct FinalNormArgs {
     half_t* out_f16 = nullptr;
     float* out_copy = nullptr;
     float* out_copy_ssq = nullptr;
+    half_t* out_copy_xh = nullptr;           // pre-scaled GEMM input of the copy's consumer ...
+    const float* out_copy_gamma = nullptr;   // ... whose norm weight this is
 };
 int launch_final_norm(hipStream_t s, const FinalNormArgs& a);
 
@@ -95,7 +102,7 @@ int launch_final_norm(hipStream_t s, const FinalNormArgs& a);
 // TalkerSampleArgs (frame = n_frames[r]-1, clamped to [0, frame_cap)).
 int launch_gather_embed(hipStream_t s, const float* table, int V, int H, const int* tok, int tok_stride,
                         const int* n_frames, int frame_cap, int col, float* h, float* ssq, int R, int row0 = 0,
-                        int R_total = 0, const int* forced = nullptr);
+                        int R_total = 0, const int* forced = nullptr, half_t* xh = nullptr, const float* gamma = nullptr);
 
 // Talker sampling (llamacpp_talker_server.py:163-206, greedy form).
 struct TalkerSampleArgs {
@@ -141,6 +148,8 @@ struct CpArgmaxArgs {
     const float* next_table = nullptr;  // f32 [V][H] of this group, or null
     float* h_out = nullptr;
     float* ssq_out = nullptr;
+    half_t* xh_out = nullptr;           // pre-scaled GEMM input for the layer that consumes h_out ...
+    const float* gamma_next = nullptr;  // ... whose input norm weight this is
     // feedback (when talker_emb != null): h_out = talker_emb[code0] + sum_g cp_tables[g][code_{g+1}] + pad
     const float* talker_emb = nullptr;
     int talker_vocab = 0;
@@ -158,7 +167,7 @@ int launch_cp_argmax(hipStream_t s, const CpArgmaxArgs& a);
 // Stand-alone feedback sum (tts_client.py:199-208) for host-provided codes.
 int launch_feedback(hipStream_t s, const int* codes16, int R, const float* talker_emb, int talker_vocab,
                     const float* const* cp_tables, int cp_vocab, int n_groups, const float* pad_embed,
-                    float* h_out, float* ssq_out, int H);
+                    float* h_out, float* ssq_out, int H, half_t* xh_out = nullptr, const float* gamma = nullptr);
 
 // diagnostic timeline build: node numbering of the launches that follow (no-op otherwise)
 int tl_next_node();

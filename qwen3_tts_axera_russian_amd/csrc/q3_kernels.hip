@@ -15,10 +15,6 @@
 //                   embedding gather, and tts_client.py:199-208 feedback sum.
 #include "q3_kernels.h"
 
-#ifndef Q3_NORM_FIRST
-#define Q3_NORM_FIRST 1
-#endif
-
 namespace q3 {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -86,6 +82,12 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ half_t sat_half(float x) {
     return (half_t)fminf(fmaxf(x, -65504.f), 65504.f);
 }
+// RMSNorm folded around the GEMM (numerics contract): the PRODUCER of a residual row also writes
+// xh = fp16((h * gamma_consumer) * NORM_PRE) -- the consumer's norm weight applied, a fixed power-of-two pre-scale
+// keeping |h * gamma| up to 1e6 inside fp16 -- and the consumer multiplies its f32 accumulators by
+// inv_rms(row) * NORM_POST.  The GEMM reads 2 bytes per activation instead of 4 and has no prologue to wait for.
+constexpr float NORM_PRE = 0.0625f, NORM_POST = 16.0f;
+__device__ __forceinline__ half_t pre_scaled(float h, float g) { return sat_half((h * g) * NORM_PRE); }
 
 // Activations that feed a GEMM (residual stream h, attention output, SwiGLU output) live in MFMA
 // A-fragment order, like the weights: 16-row x 32-k blocks (mt = m/16, kb = k/32), inside a block lane
@@ -151,7 +153,6 @@ __global__ void __launch_bounds__(NW * 64)
                   int p_swap, float p_eps, LinArgs a) {
     a.wp = p_wp;
     a.x16 = (const half_t*)p_asrc;
-    a.h = (const float*)p_asrc;
     a.ssq = p_ssq;
     a.gamma = p_gamma;
     a.y = (float*)p_out;
@@ -164,7 +165,6 @@ __global__ void __launch_bounds__(NW * 64)
     a.eps = p_eps;
     constexpr int MR = MT16 * 16, NB = NB16 * 16, NBP = NB + 4, KB = NW * KBW, K = KB * 32;
     constexpr int NTH = NW * 64;
-    constexpr bool NORM_FIRST = Q3_NORM_FIRST != 0;
     constexpr int NOUT = (EPI == EPI_SWIGLU) ? MR * NB / 2 : MR * NB;   // outputs of this workgroup
     constexpr int OPT = (NOUT + NTH - 1) / NTH;                         // outputs per thread
     constexpr int SQI = (MR * 16 + NTH - 1) / NTH;                      // ssq float4 groups per thread
@@ -183,10 +183,8 @@ __global__ void __launch_bounds__(NW * 64)
     // round trip.  vmcnt retires in order, so the few operands that gate the prologue go first, the
     // HBM weight stream next, and the L2-resident fragments (needed only together with the weights) last.
     float4 sq[SQI];
-    float4 hraw[MT16][KBW][2];
-    float4 graw[KBW][2];
     h8 af[MT16][KBW];
-    float hold[OPT];
+    float hold[OPT], gnext[OPT];
     // (a) tiny operands that gate the prologue / epilogue
     if (PRO == PRO_NORM) {
 #pragma unroll
@@ -203,53 +201,35 @@ __global__ void __launch_bounds__(NW * 64)
             const int o = tid + i * NTH;
             const int m = m0 + o / NB;
             hold[i] = 0.f;
+            gnext[i] = 0.f;
             if (o < NOUT && m < a.M) hold[i] = a.h_out[frag_idx(m, tile0 * 16 + (o % NB), a.N)];
+            if (o < NOUT && a.gamma) gnext[i] = a.gamma[tile0 * 16 + (o % NB)];   // the consumer's norm weight
         }
     }
     // (b) / (c): the weight stream (HBM, the long pole: everything this wave will need, in flight at once) and the
-    // activation fragments (L2).  PRO_F16 fragments feed the MFMA as they are: weights first, fragments last.
-    // PRO_NORM fragments still have to be scaled and rounded, so (g_norm_first) they are requested ahead of the
-    // weights: vmcnt retires in order, they land first and the conversion runs under the weight stream's latency.
+    // activation fragments (L2; fp16 in either prologue -- PRO_NORM reads the producer's pre-scaled xh).
     h8 wf[NB16][KBW];
-    auto load_weights = [&]() {
 #pragma unroll
-        for (int nb = 0; nb < NB16; nb++)
-#pragma unroll
-            for (int kbi = 0; kbi < KBW; kbi++) {
-                const h8* p = (const h8*)(a.wp + (((size_t)(tile0 + nb) * KB + (size_t)w * KBW + kbi) * 64 + lane) * 8);
-                wf[nb][kbi] = NT ? __builtin_nontemporal_load(p) : *p;
-            }
-    };
-    if (!(PRO == PRO_NORM && NORM_FIRST)) load_weights();
-    if (PRO == PRO_NORM) {
+    for (int nb = 0; nb < NB16; nb++)
 #pragma unroll
         for (int kbi = 0; kbi < KBW; kbi++) {
-            const int k0 = (w * KBW + kbi) * 32 + q * 8;
-            graw[kbi][0] = *(const float4*)(a.gamma + k0);
-            graw[kbi][1] = *(const float4*)(a.gamma + k0 + 4);
-#pragma unroll
-            for (int mt = 0; mt < MT16; mt++) {
-                // rows beyond a.M are padding of the last 16-row block (allocated, never stored from)
-                const float* hp = a.h + frag_idx(m0 + mt * 16 + c, k0, K);
-                hraw[mt][kbi][0] = *(const float4*)(hp);
-                hraw[mt][kbi][1] = *(const float4*)(hp + 4);
-            }
+            const h8* p = (const h8*)(a.wp + (((size_t)(tile0 + nb) * KB + (size_t)w * KBW + kbi) * 64 + lane) * 8);
+            wf[nb][kbi] = NT ? __builtin_nontemporal_load(p) : *p;
         }
-    } else {
 #pragma unroll
-        for (int kbi = 0; kbi < KBW; kbi++) {
-            const int k0 = (w * KBW + kbi) * 32 + q * 8;
+    for (int kbi = 0; kbi < KBW; kbi++) {
+        const int k0 = (w * KBW + kbi) * 32 + q * 8;
 #pragma unroll
-            for (int mt = 0; mt < MT16; mt++) {
-                af[mt][kbi] = *(const h8*)(a.x16 + frag_idx(m0 + mt * 16 + c, k0, K));
-            }
+        for (int mt = 0; mt < MT16; mt++) {
+            // rows beyond a.M are padding of the last 16-row block (allocated, never stored from)
+            af[mt][kbi] = *(const h8*)(a.x16 + frag_idx(m0 + mt * 16 + c, k0, K));
         }
     }
-    if (PRO == PRO_NORM && NORM_FIRST) load_weights();
     __builtin_amdgcn_sched_barrier(0);
     Q3_PH(0);  // all loads issued
 
-    // ---- 2. RMSNorm scale per row from the producer's 64 sum-of-squares partials (a.ssq_parts == 64) ----
+    // ---- 2. RMSNorm scale per row from the producer's 64 sum-of-squares partials (a.ssq_parts == 64): only the
+    // epilogue needs it (the LDS reduction's barrier orders it) ----
     if (PRO == PRO_NORM) {
 #pragma unroll
         for (int i = 0; i < SQI; i++) {
@@ -259,27 +239,8 @@ __global__ void __launch_bounds__(NW * 64)
             s += __shfl_xor(s, 4, 16);
             s += __shfl_xor(s, 2, 16);
             s += __shfl_xor(s, 1, 16);
-            if (g4 < MR * 16 && (g4 & 15) == 0) inv_s[g4 / 16] = 1.0f / sqrtf(s / (float)K + a.eps);
+            if (g4 < MR * 16 && (g4 & 15) == 0) inv_s[g4 / 16] = (1.0f / sqrtf(s / (float)K + a.eps)) * NORM_POST;
         }
-        __syncthreads();
-#pragma unroll
-        for (int kbi = 0; kbi < KBW; kbi++)
-#pragma unroll
-            for (int mt = 0; mt < MT16; mt++) {
-                const float iv = inv_s[mt * 16 + c];
-                const float4 h0 = hraw[mt][kbi][0], h1 = hraw[mt][kbi][1];
-                const float4 g0 = graw[kbi][0], g1 = graw[kbi][1];
-                h8 t;
-                t[0] = sat_half((h0.x * iv) * g0.x);
-                t[1] = sat_half((h0.y * iv) * g0.y);
-                t[2] = sat_half((h0.z * iv) * g0.z);
-                t[3] = sat_half((h0.w * iv) * g0.w);
-                t[4] = sat_half((h1.x * iv) * g1.x);
-                t[5] = sat_half((h1.y * iv) * g1.y);
-                t[6] = sat_half((h1.z * iv) * g1.z);
-                t[7] = sat_half((h1.w * iv) * g1.w);
-                af[mt][kbi] = t;
-            }
     }
 
     Q3_PH(1);  // prologue done (norm scale known, activations converted)
@@ -323,11 +284,13 @@ __global__ void __launch_bounds__(NW * 64)
                 const int m = m0 + mr;
                 const int ng = tile0 * 16 + n;
                 const bool ok = m < a.M;
+                if (PRO == PRO_NORM) v *= inv_s[mr];
                 if (EPI == EPI_STORE) {
                     if (ok) a.y[(size_t)m * a.ldy + ng] = v;
                 } else {
                     const float hn = ok ? hold[i] + v : 0.f;
                     if (ok) a.h_out[frag_idx(m, ng, a.N)] = hn;
+                    if (ok && a.xh_out) a.xh_out[frag_idx(m, ng, a.N)] = pre_scaled(hn, gnext[i]);
                     float s = hn * hn;
                     s += __shfl_xor(s, 8, 16);
                     s += __shfl_xor(s, 4, 16);
@@ -352,6 +315,10 @@ __global__ void __launch_bounds__(NW * 64)
                     u += red[(ww * MR + mr) * NBP + (2 * ii + 1) * 16 + cc];
                 }
                 const int m = m0 + mr;
+                if (PRO == PRO_NORM) {
+                    g *= inv_s[mr];
+                    u *= inv_s[mr];
+                }
                 if (m < a.M) {
                     const float sg = __fdividef(g, 1.0f + __expf(-g));   // hardware exp/rcp: ~1e-6 relative, far below the fp16 rounding that follows
                     a.act[frag_idx(m, (tile0 / NB16) * NH + j, a.N / 2)] = sat_half(sg * u);
@@ -377,7 +344,7 @@ static int launch_linear_nt(hipStream_t s, const LinArgs& a) {
     const unsigned nt_ = a.N / (16 * NB16), nr_ = (a.M - a.m_begin + MR - 1) / MR;
     b.swap_grid = nr_ > 2 ? 1 : 0;
     dim3 grid(b.swap_grid ? nr_ : nt_, b.swap_grid ? nt_ : nr_);
-    const void* asrc = PRO == PRO_F16 ? (const void*)b.x16 : (const void*)b.h;
+    const void* asrc = (const void*)b.x16;
     void* outp = EPI == EPI_STORE ? (void*)b.y : EPI == EPI_RESID ? (void*)b.h_out : (void*)b.act;
     hipLaunchKernelGGL((linear_kernel<NB16, MT16, KBW, NW, PRO, EPI, NT>), grid, dim3(NW * 64), lds, s, b.wp, asrc, b.ssq,
                        b.gamma, outp, b.M, b.N, b.m_begin, b.swap_grid, b.eps, b);
@@ -457,20 +424,34 @@ int launch_linear(hipStream_t s, const LinArgs& a, int pro, int epi) {
 // ---------------------------------------------------------------------------
 // ssq partials of uploaded rows
 // ---------------------------------------------------------------------------
-__global__ void ssq_rows_kernel(const float* __restrict__ rows, float* __restrict__ h, float* __restrict__ ssq, int H) {
-    const int r = blockIdx.x;
-    for (int k4 = threadIdx.x; k4 < H / 4; k4 += blockDim.x) {
-        const float4 v = *(const float4*)(rows + (size_t)r * H + k4 * 4);
-        *(float4*)(h + frag_idx(r, k4 * 4, H)) = v;
-        float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-        s += __shfl_xor(s, 1, 4);
-        s += __shfl_xor(s, 2, 4);
-        if ((k4 & 3) == 0) ssq[(size_t)r * (H / 16) + (k4 >> 2)] = s;
+// A residual row leaves its producer as: h (f32), 64 sum-of-squares partials, and xh = the consumer's pre-scaled
+// fp16 GEMM input (see NORM_PRE); gamma = the consuming layer's norm weight (null: no xh).
+__device__ __forceinline__ void store_row_ssq(float* h, float* ssq, int r, int H, int k4, float4 v,
+                                              half_t* xh = nullptr, const float* gamma = nullptr) {
+    *(float4*)(h + frag_idx(r, k4 * 4, H)) = v;
+    if (xh) {
+        const float4 g = *(const float4*)(gamma + k4 * 4);
+        half_t* p = xh + frag_idx(r, k4 * 4, H);
+        p[0] = pre_scaled(v.x, g.x);
+        p[1] = pre_scaled(v.y, g.y);
+        p[2] = pre_scaled(v.z, g.z);
+        p[3] = pre_scaled(v.w, g.w);
     }
+    float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    s += __shfl_xor(s, 1, 4);
+    s += __shfl_xor(s, 2, 4);
+    if ((k4 & 3) == 0) ssq[(size_t)r * (H / 16) + (k4 >> 2)] = s;
 }
-int launch_ssq_rows(hipStream_t s, const float* rows, float* h, float* ssq, int R, int H) {
+
+__global__ void ssq_rows_kernel(const float* __restrict__ rows, float* __restrict__ h, float* __restrict__ ssq, int H,
+                                half_t* __restrict__ xh, const float* __restrict__ gamma) {
+    const int r = blockIdx.x;
+    for (int k4 = threadIdx.x; k4 < H / 4; k4 += blockDim.x)
+        store_row_ssq(h, ssq, r, H, k4, *(const float4*)(rows + (size_t)r * H + k4 * 4), xh, gamma);
+}
+int launch_ssq_rows(hipStream_t s, const float* rows, float* h, float* ssq, int R, int H, half_t* xh, const float* gamma) {
     if (R <= 0) return 0;
-    hipLaunchKernelGGL(ssq_rows_kernel, dim3(R), dim3(256), 0, s, rows, h, ssq, H);
+    hipLaunchKernelGGL(ssq_rows_kernel, dim3(R), dim3(256), 0, s, rows, h, ssq, H, xh, gamma);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
 }
@@ -507,13 +488,7 @@ __global__ void final_norm_kernel(FinalNormArgs a) {
             p[2] = sat_half(o.z);
             p[3] = sat_half(o.w);
         }
-        if (a.out_copy) {
-            *(float4*)(a.out_copy + frag_idx(r, k4 * 4, a.H)) = o;
-            float s = o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
-            s += __shfl_xor(s, 1, 4);
-            s += __shfl_xor(s, 2, 4);
-            if ((k4 & 3) == 0) a.out_copy_ssq[(size_t)r * (a.H / 16) + (k4 >> 2)] = s;
-        }
+        if (a.out_copy) store_row_ssq(a.out_copy, a.out_copy_ssq, r, a.H, k4, o, a.out_copy_xh, a.out_copy_gamma);
     }
 }
 int launch_final_norm(hipStream_t s, const FinalNormArgs& a) {
@@ -528,18 +503,11 @@ int launch_final_norm(hipStream_t s, const FinalNormArgs& a) {
 // ---------------------------------------------------------------------------
 // embedding gather with ssq partials
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void store_row_ssq(float* h, float* ssq, int r, int H, int k4, float4 v) {
-    *(float4*)(h + frag_idx(r, k4 * 4, H)) = v;
-    float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-    s += __shfl_xor(s, 1, 4);
-    s += __shfl_xor(s, 2, 4);
-    if ((k4 & 3) == 0) ssq[(size_t)r * (H / 16) + (k4 >> 2)] = s;
-}
-
 __global__ void gather_embed_kernel(const float* __restrict__ table, int V, int H, const int* __restrict__ tok,
                                     int tok_stride, const int* __restrict__ n_frames, int frame_cap, int col,
                                     float* __restrict__ h, float* __restrict__ ssq, int row0, int R_total,
-                                    const int* __restrict__ forced) {
+                                    const int* __restrict__ forced, half_t* __restrict__ xh,
+                                    const float* __restrict__ gamma) {
     const int r = row0 + blockIdx.x;
     int t;
     if (n_frames) {
@@ -558,15 +526,15 @@ __global__ void gather_embed_kernel(const float* __restrict__ table, int V, int 
     for (int k4 = threadIdx.x; k4 < H / 4; k4 += blockDim.x) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok) v = *(const float4*)(table + (size_t)t * H + k4 * 4);
-        store_row_ssq(h, ssq, r, H, k4, v);
+        store_row_ssq(h, ssq, r, H, k4, v, xh, gamma);
     }
 }
 int launch_gather_embed(hipStream_t s, const float* table, int V, int H, const int* tok, int tok_stride,
                         const int* n_frames, int frame_cap, int col, float* h, float* ssq, int R, int row0,
-                        int R_total, const int* forced) {
+                        int R_total, const int* forced, half_t* xh, const float* gamma) {
     if (R <= 0) return 0;
     hipLaunchKernelGGL(gather_embed_kernel, dim3(R), dim3(256), 0, s, table, V, H, tok, tok_stride, n_frames,
-                       frame_cap, col, h, ssq, row0, R_total > 0 ? R_total : R, forced);
+                       frame_cap, col, h, ssq, row0, R_total > 0 ? R_total : R, forced, xh, gamma);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
 }
@@ -1260,7 +1228,8 @@ int launch_talker_sample(hipStream_t s, const TalkerSampleArgs& a) {
 __device__ __forceinline__ void feedback_row(const int* codes, int r, const float* talker_emb, int talker_vocab,
                                              const float* const* cp_tables, int cp_vocab, int n_groups,
                                              const float* pad, float* h_out, float* ssq_out, int H,
-                                             int ov_g = -1, int ov_tok = 0, const int* fz = nullptr) {
+                                             int ov_g = -1, int ov_tok = 0, const int* fz = nullptr,
+                                             half_t* xh_out = nullptr, const float* gamma = nullptr) {
     // tts_client.py:199-208: copy codec_embedding[code_0], += cp table g row, += tts_pad, in this order
     // (fz: teacher-forced ids of this frame, tests only -- entries >= 0 replace the recorded decisions)
     int c0 = codes[0];
@@ -1286,7 +1255,7 @@ __device__ __forceinline__ void feedback_row(const int* codes, int r, const floa
             v.z += e.z;
             v.w += e.w;
         }
-        store_row_ssq(h_out, ssq_out, r, H, k4, v);
+        store_row_ssq(h_out, ssq_out, r, H, k4, v, xh_out, gamma);
     }
 }
 
@@ -1376,11 +1345,11 @@ __global__ void __launch_bounds__(256) cp_argmax_kernel(CpArgmaxArgs a) {
     Q3_PH(2);
     if (a.talker_emb) {
         feedback_row(fc, r, a.talker_emb, a.talker_vocab, a.cp_tables, a.V, a.n_groups, a.pad_embed,
-                     a.h_out, a.ssq_out, a.H, a.group, bidx, fz);
+                     a.h_out, a.ssq_out, a.H, a.group, bidx, fz, a.xh_out, a.gamma_next);
     } else if (a.next_table) {
         for (int k4 = tid; k4 < a.H / 4; k4 += 256) {
             const float4 v = *(const float4*)(a.next_table + (size_t)bidx * a.H + k4 * 4);
-            store_row_ssq(a.h_out, a.ssq_out, r, a.H, k4, v);
+            store_row_ssq(a.h_out, a.ssq_out, r, a.H, k4, v, a.xh_out, a.gamma_next);
         }
     }
 }
@@ -1401,16 +1370,16 @@ int launch_cp_argmax(hipStream_t s, const CpArgmaxArgs& a) {
 
 __global__ void feedback_kernel(const int* codes, const float* talker_emb, int talker_vocab,
                                 const float* const* cp_tables, int cp_vocab, int n_groups, const float* pad,
-                                float* h_out, float* ssq_out, int H) {
+                                float* h_out, float* ssq_out, int H, half_t* xh_out, const float* gamma) {
     feedback_row(codes + (size_t)blockIdx.x * 16, blockIdx.x, talker_emb, talker_vocab, cp_tables, cp_vocab, n_groups,
-                 pad, h_out, ssq_out, H);
+                 pad, h_out, ssq_out, H, -1, 0, nullptr, xh_out, gamma);
 }
 int launch_feedback(hipStream_t s, const int* codes16, int R, const float* talker_emb, int talker_vocab,
                     const float* const* cp_tables, int cp_vocab, int n_groups, const float* pad_embed,
-                    float* h_out, float* ssq_out, int H) {
+                    float* h_out, float* ssq_out, int H, half_t* xh_out, const float* gamma) {
     if (R <= 0) return 0;
     hipLaunchKernelGGL(feedback_kernel, dim3(R), dim3(256), 0, s, codes16, talker_emb, talker_vocab, cp_tables,
-                       cp_vocab, n_groups, pad_embed, h_out, ssq_out, H);
+                       cp_vocab, n_groups, pad_embed, h_out, ssq_out, H, xh_out, gamma);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
 }

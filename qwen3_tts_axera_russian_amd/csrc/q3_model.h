@@ -17,6 +17,9 @@ struct DevLayer {
 struct DevStack {
     std::vector<DevLayer> L;
     float* final_norm = nullptr;
+    // norm weight of whatever consumes the stack's output THROUGH A GEMM (code predictor: final_norm, the group
+    // heads read the last layer's xh); null when the output is only normed element-wise (talker)
+    const float* tail_gamma = nullptr;
     int ffn = 0;
     int nt = 0;  // non-temporal weight stream
     size_t weight_bytes = 0;
@@ -61,6 +64,7 @@ struct Work {
     int max_rows = 0, hidden = 0;   // max_rows is padded to a multiple of 64 (largest row tile)
     float* rows_in = nullptr;       // row-major staging of uploaded embedding rows
     float *h = nullptr, *ssq = nullptr, *qkv = nullptr;   // h: fragment order
+    half_t* xh = nullptr;          // fp16((h*gamma_consumer)/16), fragment order: the next normed GEMM's input
     half_t *attn = nullptr, *act = nullptr;
     float* hidden_f32 = nullptr;   // post-final-norm
     half_t* hidden_f16 = nullptr;

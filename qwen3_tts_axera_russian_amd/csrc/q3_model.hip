@@ -182,6 +182,7 @@ Model* model_load(const char* path, bool want_talker, bool want_cp, const char* 
     if (want_cp && L.ok) {
         m->cp.nt = 0;
         L.load_stack(m->cp, "cp", c.cp_layers, c.cp_ffn);
+        m->cp.tail_gamma = m->cp.final_norm;   // the group heads are GEMMs over the final-normed output
         m->cp_emb.resize(c.cp_groups);
         m->cp_head.resize(c.cp_groups);
         for (int g = 0; g < c.cp_groups && L.ok; g++) {
@@ -265,6 +266,8 @@ int work_alloc(Work& w, const ModelCfg& c, int max_rows, int ffn, int max_vocab)
     Q3_HIP(hipMalloc((void**)&w.h, R * c.hidden * 4), -1);
     Q3_HIP(hipMemset(w.h, 0, R * c.hidden * 4), -1);
     Q3_HIP(hipMalloc((void**)&w.ssq, R * (c.hidden / 16) * 4), -1);
+    Q3_HIP(hipMalloc((void**)&w.xh, R * c.hidden * 2), -1);
+    Q3_HIP(hipMemset(w.xh, 0, R * c.hidden * 2), -1);
     Q3_HIP(hipMalloc((void**)&w.qkv, R * qkv_ld * 4), -1);
     Q3_HIP(hipMalloc((void**)&w.attn, R * c.n_heads * c.head_dim * 2), -1);
     Q3_HIP(hipMemset(w.attn, 0, R * c.n_heads * c.head_dim * 2), -1);
@@ -277,7 +280,7 @@ int work_alloc(Work& w, const ModelCfg& c, int max_rows, int ffn, int max_vocab)
     return 0;
 }
 void work_free(Work& w) {
-    void* ps[] = {w.rows_in, w.h, w.ssq, w.qkv, w.attn, w.act, w.hidden_f32, w.hidden_f16, w.logits};
+    void* ps[] = {w.rows_in, w.h, w.ssq, w.xh, w.qkv, w.attn, w.act, w.hidden_f32, w.hidden_f16, w.logits};
     for (void* p : ps)
         if (p) hipFree(p);
     w = Work();
@@ -307,10 +310,9 @@ int run_stack(hipStream_t s, const Model& m, const DevStack& st, Work& w, KVCach
         a.M = row0 + R;
         a.m_begin = row0;
         a.nt = st.nt;
-        a.h = w.h;
+        a.x16 = w.xh;          // fp16((h * in_ln) / 16), written by the producer of h
         a.ssq = w.ssq;
         a.ssq_parts = H / 16;
-        a.gamma = L.in_ln;
         a.eps = c.eps;
         a.y = w.qkv;
         a.ldy = qkv_ld;
@@ -357,6 +359,8 @@ int run_stack(hipStream_t s, const Model& m, const DevStack& st, Work& w, KVCach
         a.x16 = w.attn;
         a.h_out = w.h;
         a.ssq_out = w.ssq;
+        a.xh_out = w.xh;
+        a.gamma = L.post_ln;   // consumer: this layer's gate/up
         if (launch_linear(s, a, PRO_F16, EPI_RESID)) return -1;
         // gate/up + SwiGLU
         a = LinArgs();
@@ -366,10 +370,9 @@ int run_stack(hipStream_t s, const Model& m, const DevStack& st, Work& w, KVCach
         a.M = row0 + R;
         a.m_begin = row0;
         a.nt = st.nt;
-        a.h = w.h;
+        a.x16 = w.xh;
         a.ssq = w.ssq;
         a.ssq_parts = H / 16;
-        a.gamma = L.post_ln;
         a.eps = c.eps;
         a.act = w.act;
         if (launch_linear(s, a, PRO_NORM, EPI_SWIGLU)) return -1;
@@ -384,6 +387,9 @@ int run_stack(hipStream_t s, const Model& m, const DevStack& st, Work& w, KVCach
         a.x16 = w.act;
         a.h_out = w.h;
         a.ssq_out = w.ssq;
+        // consumer: the next layer's q/k/v, or whatever GEMM reads the stack's output (st.tail_gamma)
+        a.gamma = li + 1 < st.L.size() ? st.L[li + 1].in_ln : st.tail_gamma;
+        a.xh_out = a.gamma ? w.xh : nullptr;
         if (launch_linear(s, a, PRO_F16, EPI_RESID)) return -1;
     }
     return 0;

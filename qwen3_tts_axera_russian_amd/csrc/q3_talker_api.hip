@@ -32,7 +32,7 @@ int attn_threads_for(int n_ctx) { return n_ctx <= 64 ? 256 : 1024; }
 // rows already in w.h (f32) -> hidden of `out_rows` rows (row_map on device or null = identity)
 int forward_rows(TalkerCtx* c, int R, const RowMap& rm) {
     const Model& m = *c->tm->m;
-    if (launch_ssq_rows(c->s, c->w.rows_in, c->w.h, c->w.ssq, R, m.cfg.hidden)) return -1;
+    if (launch_ssq_rows(c->s, c->w.rows_in, c->w.h, c->w.ssq, R, m.cfg.hidden, c->w.xh, m.talker.L[0].in_ln)) return -1;
     if (run_stack(c->s, m, m.talker, c->w, c->kv, R, rm, attn_threads_for(c->n_ctx))) return -1;
     return 0;
 }

@@ -40,7 +40,7 @@ int q3t_linear(int M, int N, int K, const uint16_t* W, int gateup, int pro, int 
                int nt) {
     hipStream_t s = nullptr;
     const int Mp = (M + 63) / 64 * 64;  // buffers padded to the largest row tile
-    DBuf dW, dWp, dx, dhrows, dh, dssq, dg, dy, dso, dact;
+    DBuf dW, dWp, dx, dhrows, dh, dssq, dg, dy, dso, dact, dxh;
     if (!dW.up(W, (size_t)N * K * 2) || !dWp.alloc((size_t)N * K * 2)) return -1;
     if (gateup) {
         if (launch_pack_linear(s, (const half_t*)dW.p, N / 2, K, (half_t*)dWp.p, 0, 2)) return -1;
@@ -65,11 +65,13 @@ int q3t_linear(int M, int N, int K, const uint16_t* W, int gateup, int pro, int 
             !dg.up(gamma, (size_t)K * 4))
             return -1;
         hipMemset(dh.p, 0, (size_t)Mp * K * 4);
-        if (launch_ssq_rows(s, (const float*)dhrows.p, (float*)dh.p, (float*)dssq.p, M, K)) return -1;
-        a.h = (const float*)dh.p;
+        if (!dxh.alloc((size_t)Mp * K * 2)) return -1;
+        hipMemset(dxh.p, 0, (size_t)Mp * K * 2);
+        // the producer's side of the folded RMSNorm: h, its sum-of-squares partials and xh = fp16((h*gamma)/16)
+        if (launch_ssq_rows(s, (const float*)dhrows.p, (float*)dh.p, (float*)dssq.p, M, K, (half_t*)dxh.p, (const float*)dg.p)) return -1;
+        a.x16 = (const half_t*)dxh.p;
         a.ssq = (const float*)dssq.p;
         a.ssq_parts = K / 16;
-        a.gamma = (const float*)dg.p;
         a.eps = eps;
     }
     std::vector<float> hp;
@@ -134,10 +136,8 @@ float q3t_bench_linear(int M, int N, int K, int pro, int epi, int nt, int n_copi
     a.M = Mreal;
     a.nt = nt;
     a.x16 = (const half_t*)dx.p;
-    a.h = (const float*)dh.p;
     a.ssq = (const float*)dssq.p;
     a.ssq_parts = K / 16;
-    a.gamma = (const float*)dg.p;
     a.y = (float*)dy.p;
     a.ldy = N;
     a.h_out = (float*)dy.p;

@@ -30,9 +30,11 @@ def _run_linear(lib, M, N, K, W16, gateup, pro, epi, x16=None, h=None, gamma=Non
     return y, ssq, act
 
 
-def _norm_round(h, gamma, eps):
+def _norm_fold(h, gamma, eps):
+    """The folded RMSNorm of the numerics contract: GEMM input fp16((h*gamma)/16), GEMM results
+    times 16*inv_rms(row)."""
     inv = 1.0 / np.sqrt((h.astype(np.float64) ** 2).mean(axis=1, keepdims=True) + eps)
-    return ((h * inv.astype(np.float32)) * gamma).astype(np.float16)
+    return ((h * gamma) * np.float32(0.0625)).astype(np.float16), (inv * 16.0).astype(np.float32)
 
 
 @pytest.mark.parametrize("M", [1, 3, 16, 17, 32, 45, 64, 100])
@@ -60,18 +62,19 @@ def test_linear_norm_prologue_and_swiglu(test_lib, M):
     K, F = 1024, 3072
     h = (3.0 * rng.standard_normal((M, K))).astype(np.float32)
     gamma = (1.0 + 0.1 * rng.standard_normal(K)).astype(np.float32)
-    xr = _norm_round(h, gamma, 1e-6).astype(np.float32)
+    xr, post = _norm_fold(h, gamma, 1e-6)
+    xr = xr.astype(np.float32)
     # q/k/v-shaped store
     W = _h(0.05 * rng.standard_normal((4096, K)))
     y, _, _ = _run_linear(test_lib, M, 4096, K, W, 0, 1, 0, h=h, gamma=gamma)
-    ref = xr @ W.astype(np.float32).T
+    ref = (xr @ W.astype(np.float32).T) * post
     # a norm-input rounding flip (1 fp16 ulp on one element) moves an output by <= 2^-11*|x|*|w|
     np.testing.assert_allclose(y, ref, rtol=0, atol=1e-3 * np.abs(ref).max())
     # gate/up + SwiGLU; weights: rows [0,F) gate, [F,2F) up
     Wgu = _h(0.05 * rng.standard_normal((2 * F, K)))
     _, _, act = _run_linear(test_lib, M, 2 * F, K, Wgu, 1, 1, 2, h=h, gamma=gamma)
-    g = xr @ Wgu[:F].astype(np.float32).T
-    u = xr @ Wgu[F:].astype(np.float32).T
+    g = (xr @ Wgu[:F].astype(np.float32).T) * post
+    u = (xr @ Wgu[F:].astype(np.float32).T) * post
     ref_act = (g / (1.0 + np.exp(-g))) * u
     np.testing.assert_allclose(act.astype(np.float32), ref_act, rtol=2e-3, atol=2e-3 * np.abs(ref_act).max())
 

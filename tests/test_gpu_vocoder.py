@@ -149,6 +149,33 @@ def test_full_size_table_is_causal_and_deterministic(gpu_lib, tmp_path_factory):
     v.close()
 
 
+def test_full_size_table_matches_torch_reference_in_both_arithmetic_modes(gpu_lib):
+    """Numerics (not only properties) at the FULL default table -- the vocoder the benchmark times, with its
+    96-row / 128- and 256-column tiles, XCD tile order and every kernel variant of the 1536 -> 96 channel trunk:
+    one 64-frame chunk against oracle/voc_ref.py (torch CPU fp32, ~1 s) in the exact-fp32 mode and in the
+    2 x fp16 split-operand mode, tolerance 2e-4 of full scale (the waveform is clamped to [-1, 1]); plus the
+    second chunk of a batch of two, so the batch index of the tiling is covered."""
+    path = os.path.join(CACHE, "voc_full_s1234.q3w")
+    if not os.path.exists(path):
+        W.write_pack(path, {"voc_chunk": 64.0}, W.make_synthetic_voc(W.VocConfig(), seed=1234))
+    _, tensors = W.read_pack(path)
+    rng = np.random.default_rng(21)
+    codes = rng.integers(0, 2048, size=(2, 64, 16)).astype(np.int64)
+    ref = voc_reference(tensors, codes)
+    assert ref.shape == (2, 64 * 1920) and np.abs(ref).max() > 0.01
+    for exact in (1, 0):
+        gpu_lib.voc_set_exact_fp32(exact)
+        v = Voc(gpu_lib, path, max_batch=2)
+        out = v.decode(codes).copy()
+        one = v.decode(codes[1:2]).copy()
+        v.close()
+        err = float(np.abs(out - ref).max())
+        print(f"full-size table, exact={exact}: max abs err vs torch fp32 {err:.2e} (signal max {np.abs(ref).max():.3f})")
+        assert err < 2e-4
+        np.testing.assert_array_equal(one[0], out[1])
+    gpu_lib.voc_set_exact_fp32(0)
+
+
 @pytest.fixture(scope="module")
 def tiny_full_voc():
     os.makedirs(CACHE, exist_ok=True)

@@ -65,3 +65,27 @@ def test_oracle_cp_loop_equals_reference_shaped_python_loop():
     heads = [np.asarray(a) for a in cp.heads]
     toks = fe.cp_predict_loop(step, hidden, 321, cp.talker_emb, cp.emb, heads)
     assert [int(x) for x in codes] == toks
+
+
+def test_oracle_batched_pipeline_equals_per_utterance_pipeline():
+    """oracle/pipeline.CpuPipeline.generate_batch (weights read once per pass for the whole batch -- what makes the
+    full-depth 32-utterance GPU parity test affordable) is, per utterance, bit-identical to generate(): ids AND
+    margins, including an utterance the adaptive EOS boost ends early."""
+    from oracle.pipeline import CpuPipeline
+    from tests.util import synthetic_pack
+    path, cfg, tensors = synthetic_pack(2, 2)
+    cpu = CpuPipeline(cfg, tensors, n_ctx=64)
+    rng = np.random.default_rng(72)
+    lens, n_text = [12, 21, 17, 9], [30, 12, 3, 25]
+    prefixes = [(0.05 * rng.standard_normal((n, 1024))).astype(np.float32) for n in lens]
+    pad = (0.05 * rng.standard_normal(1024)).astype(np.float32)
+    frames_b, margins_b = cpu.generate_batch(prefixes, n_text, pad, 10)
+    ended_early = 0
+    for b in range(4):
+        fr, mm = cpu.generate(prefixes[b], n_text[b], pad, 10, want_margins=True)
+        assert fr == frames_b[b]
+        assert len(mm) == len(margins_b[b])
+        for x, y in zip(mm, margins_b[b]):
+            np.testing.assert_array_equal(np.asarray(x, np.float64), np.asarray(y, np.float64))
+        ended_early += len(fr) < 10
+    assert ended_early >= 1
