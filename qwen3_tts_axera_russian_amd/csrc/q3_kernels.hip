@@ -352,6 +352,176 @@ static int launch_linear_nt(hipStream_t s, const LinArgs& a) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// gemm_kernel<BM, BN, PRO, EPI> -- the same linear layers for MANY rows (prefill: llama_wrapper.c:125-163 with
+// n_tokens = n_text + 9, all utterances of a batch in one ragged pass).  A real tiled GEMM: workgroup = 4 waves
+// (2 x 2), tile BM x BN, each wave (BM/2) x (BN/2) as 16x16x32 f16 MFMA fragments; per stage 64 k of the A tile
+// (activations, already in fragment order) and of the B tile (weights, fragment order) go global -> registers ->
+// LDS, double buffered, one barrier per stage; every fragment is one conflict-free ds_read_b128.  The operands,
+// prologue/epilogue semantics and output layouts are exactly linear_kernel's, so the two are interchangeable
+// per launch (launch_linear picks by row count).
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int KS, int PRO, int EPI>
+__global__ void __launch_bounds__(256) gemm_kernel(LinArgs a) {
+    // KS = k-blocks (32 k each) per stage.  A stage is bounded by the latency of its own global loads (one stage is
+    // prefetched while the previous one computes: ~2000 cycles against ~128 * KS cycles of MFMA work), so stages are
+    // made as deep as LDS allows: 2 buffers x (BM + BN) / 16 x KS KiB = 128 KiB.
+    constexpr int RA = BM / 16, RB = BN / 16;                   // row / column fragments of the tile
+    constexpr int NF = (RA + RB) * KS, FPW = NF / 4;            // fragments per stage, per wave to fetch
+    constexpr int WM = BM / 32, WN = BN / 32;                   // fragments per wave (rows, columns)
+    static_assert(NF % 4 == 0 && WN % 2 == 0, "tile shape");
+    Q3_TL(20 + PRO * 4 + EPI);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1, q = lane >> 4, c = lane & 15;
+    const int m0 = a.m_begin + blockIdx.x * BM;                 // row tile = fast grid index: the workgroups sharing a
+    const int tile0 = blockIdx.y * RB;                          // weight tile run together, it is streamed from HBM once
+    const int KB = a.K >> 5, NST = KB / KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    h8* lds = (h8*)smem;                                        // [2][NF][64] fragments
+    __shared__ float post[BM];
+    if (PRO == PRO_NORM) {
+        for (int r = tid; r < BM; r += 256) {
+            const int m = m0 + r;
+            float sum = 0.f;
+            if (m < a.M) {
+                const float4* sp = (const float4*)(a.ssq + (size_t)m * 64);
+#pragma unroll
+                for (int p = 0; p < 16; p++) {
+                    const float4 v = sp[p];
+                    sum += (v.x + v.y) + (v.z + v.w);
+                }
+            }
+            post[r] = (1.0f / sqrtf(sum / (float)a.K + a.eps)) * NORM_POST;
+        }
+    }
+    const size_t arow = (size_t)(m0 >> 4) * KB;
+    auto frag_ptr = [&](int f, int kb0) -> const h8* {
+        if (f < RA * KS) {
+            const int rb = f / KS, kk = f % KS;
+            return (const h8*)(a.x16 + ((arow + (size_t)rb * KB + kb0 + kk) * 64 + lane) * 8);
+        }
+        const int g = f - RA * KS, t = g / KS, kk = g % KS;
+        return (const h8*)(a.wp + (((size_t)(tile0 + t) * KB + kb0 + kk) * 64 + lane) * 8);
+    };
+    h8 st[FPW];
+#pragma unroll
+    for (int i = 0; i < FPW; i++) st[i] = *frag_ptr(w * FPW + i, 0);
+#pragma unroll
+    for (int i = 0; i < FPW; i++) lds[(w * FPW + i) * 64 + lane] = st[i];
+    f4 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    for (int ks = 0; ks < NST; ks++) {
+        const bool more = ks + 1 < NST;
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < FPW; i++) st[i] = *frag_ptr(w * FPW + i, (ks + 1) * KS);
+        }
+        const h8* cur = lds + (size_t)(ks & 1) * NF * 64;
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) {
+            h8 af[WM], bf[WN];
+#pragma unroll
+            for (int i = 0; i < WM; i++) af[i] = cur[((wm * WM + i) * KS + kk) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < WN; j++) bf[j] = cur[(RA * KS + (wn * WN + j) * KS + kk) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < WM; i++)
+#pragma unroll
+                for (int j = 0; j < WN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            h8* nxt = lds + (size_t)((ks + 1) & 1) * NF * 64;
+#pragma unroll
+            for (int i = 0; i < FPW; i++) nxt[(w * FPW + i) * 64 + lane] = st[i];
+        }
+        __syncthreads();
+    }
+    // ---- epilogue straight from the accumulators.  D layout: column = lane & 15, row = 4 * (lane >> 4) + reg ----
+#pragma unroll
+    for (int i = 0; i < WM; i++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int mr = (wm * WM + i) * 16 + 4 * q + r;
+            const int m = m0 + mr;
+            const bool ok = m < a.M;
+            const float ps = PRO == PRO_NORM ? post[mr] : 1.0f;
+            if (EPI == EPI_SWIGLU) {
+#pragma unroll
+                for (int j = 0; j < WN; j += 2) {
+                    const float g = acc[i][j][r] * ps, u = acc[i][j + 1][r] * ps;
+                    const float sg = __fdividef(g, 1.0f + __expf(-g));
+                    const int jn = ((tile0 + wn * WN + j) >> 1) * 16 + c;     // column of act[M][N/2]
+                    if (ok) a.act[frag_idx(m, jn, a.N / 2)] = sat_half(sg * u);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < WN; j++) {
+                    const int ng = (tile0 + wn * WN + j) * 16 + c;
+                    const float v = acc[i][j][r] * ps;
+                    if (EPI == EPI_STORE) {
+                        if (ok) a.y[(size_t)m * a.ldy + ng] = v;
+                    } else {
+                        const size_t hi = frag_idx(m, ng, a.N);
+                        const float hn = ok ? a.h_out[hi] + v : 0.f;
+                        if (ok) a.h_out[hi] = hn;
+                        if (ok && a.xh_out) a.xh_out[hi] = pre_scaled(hn, a.gamma[ng]);
+                        float s2 = hn * hn;
+                        s2 += __shfl_xor(s2, 8, 16);
+                        s2 += __shfl_xor(s2, 4, 16);
+                        s2 += __shfl_xor(s2, 2, 16);
+                        s2 += __shfl_xor(s2, 1, 16);
+                        if (ok && c == 0) a.ssq_out[(size_t)m * (a.N / 16) + (ng >> 4)] = s2;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int PRO, int EPI>
+static int launch_gemm_t(hipStream_t s, const LinArgs& a) {
+    constexpr int KS = 1024 / (BM + BN);    // 128 x 128: 4 k-blocks (128 k) per stage; 64 x 64: 8
+    constexpr size_t lds = (size_t)2 * ((BM + BN) / 16) * KS * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (lds > 48 * 1024)
+            Q3_HIP(hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, KS, PRO, EPI>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), -1);
+        attr_set = true;
+    }
+    LinArgs b = a;
+    b.tl_node = tl_next_node();
+    dim3 grid((a.M - a.m_begin + BM - 1) / BM, a.N / BN);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, KS, PRO, EPI>), grid, dim3(256), lds, s, b);
+    Q3_HIP(hipGetLastError(), -1);
+    return 0;
+}
+
+// rows beyond this use the tiled GEMM (buffers are padded to GEMM_ROW_PAD rows)
+static int g_gemm_min_rows = 65;
+int set_gemm_min_rows(int n) { g_gemm_min_rows = n; return 0; }
+
+static int launch_gemm(hipStream_t s, const LinArgs& a, int pro, int epi) {
+    if (a.m_begin % 16 || a.K % 256 || a.N % 128 || (pro == PRO_NORM && a.ssq_parts != 64)) {
+        Q3_LOG("launch_gemm: unsupported shape N=%d K=%d m_begin=%d", a.N, a.K, a.m_begin);
+        return -1;
+    }
+    const bool narrow = a.N <= 2048;   // o / down (N = 1024): 64 x 64 tiles, else too few workgroups to fill 256 CUs
+    if (pro == PRO_NORM && epi == EPI_STORE) return launch_gemm_t<128, 128, PRO_NORM, EPI_STORE>(s, a);
+    if (pro == PRO_NORM && epi == EPI_SWIGLU) return launch_gemm_t<128, 128, PRO_NORM, EPI_SWIGLU>(s, a);
+    if (pro == PRO_F16 && epi == EPI_RESID)
+        return narrow ? launch_gemm_t<64, 64, PRO_F16, EPI_RESID>(s, a) : launch_gemm_t<128, 128, PRO_F16, EPI_RESID>(s, a);
+    if (pro == PRO_F16 && epi == EPI_STORE)
+        return narrow ? launch_gemm_t<64, 64, PRO_F16, EPI_STORE>(s, a) : launch_gemm_t<128, 128, PRO_F16, EPI_STORE>(s, a);
+    Q3_LOG("launch_gemm: no instantiation for pro=%d epi=%d", pro, epi);
+    return -1;
+}
+
 template <int NB16, int MT16, int KBW, int NW, int PRO, int EPI>
 static int launch_linear_t(hipStream_t s, const LinArgs& a) {
     return a.nt ? launch_linear_nt<NB16, MT16, KBW, NW, PRO, EPI, true>(s, a)
@@ -385,6 +555,7 @@ int set_linear_tuning(int K, int mt16, int kbw) {
 int launch_linear(hipStream_t s, const LinArgs& a, int pro, int epi) {
     const int rows = a.M - a.m_begin;
     if (rows <= 0) return 0;
+    if (rows >= g_gemm_min_rows) return launch_gemm(s, a, pro, epi);
     const int K = a.K;
     int ki = K == 1024 ? 0 : K == 2048 ? 1 : K == 3072 ? 2 : -1;
     if (ki < 0 || a.N % 32) {

@@ -61,7 +61,7 @@ inline size_t frag_idx_host(int m, int k, int K) {
 }
 
 struct Work {
-    int max_rows = 0, hidden = 0;   // max_rows is padded to a multiple of 64 (largest row tile)
+    int max_rows = 0, hidden = 0;   // max_rows is padded to a multiple of 128 (largest row tile)
     float* rows_in = nullptr;       // row-major staging of uploaded embedding rows
     float *h = nullptr, *ssq = nullptr, *qkv = nullptr;   // h: fragment order
     half_t* xh = nullptr;          // fp16((h*gamma_consumer)/16), fragment order: the next normed GEMM's input

@@ -257,7 +257,7 @@ void kv_free(KVCache& kv) {
 }
 
 int work_alloc(Work& w, const ModelCfg& c, int max_rows, int ffn, int max_vocab) {
-    max_rows = (max_rows + 63) / 64 * 64;
+    max_rows = (max_rows + 127) / 128 * 128;   // the largest row tile (gemm_kernel: 128)
     w.max_rows = max_rows;
     w.hidden = c.hidden;
     const size_t R = (size_t)max_rows;

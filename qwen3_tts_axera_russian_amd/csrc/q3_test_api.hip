@@ -11,6 +11,7 @@ int set_linear_tuning(int K, int mt16, int kbw);
 int set_linear_split_rows(int on);
 int set_linear_wide_tiles(int on);
 int set_attn_short(int on);
+int set_gemm_min_rows(int n);
 }
 
 namespace {
@@ -30,6 +31,8 @@ int q3t_set_linear_tuning(int K, int mt16, int kbw) { return set_linear_tuning(K
 int q3t_set_linear_split_rows(int on) { return set_linear_split_rows(on); }
 int q3t_set_linear_wide_tiles(int on) { return set_linear_wide_tiles(on); }
 int q3t_set_attn_short(int on) { return set_attn_short(on); }
+// rows >= n take the tiled GEMM (gemm_kernel) instead of the weight-streaming kernel; default 65
+int q3t_set_gemm_min_rows(int n) { return set_gemm_min_rows(n); }
 
 // One linear launch.  W is row-major fp16 [N][K]; gateup != 0 means rows [0,N/2) are gate and
 // [N/2,N) up (tile-interleaved on the device like the model loader does).
@@ -39,7 +42,7 @@ int q3t_linear(int M, int N, int K, const uint16_t* W, int gateup, int pro, int 
                const float* h, const float* gamma, float eps, float* y_or_h_io, float* ssq_out, uint16_t* act_out,
                int nt) {
     hipStream_t s = nullptr;
-    const int Mp = (M + 63) / 64 * 64;  // buffers padded to the largest row tile
+    const int Mp = (M + 127) / 128 * 128;  // buffers padded to the largest row tile
     DBuf dW, dWp, dx, dhrows, dh, dssq, dg, dy, dso, dact, dxh;
     if (!dW.up(W, (size_t)N * K * 2) || !dWp.alloc((size_t)N * K * 2)) return -1;
     if (gateup) {
@@ -115,7 +118,7 @@ float q3t_bench_linear(int M, int N, int K, int pro, int epi, int nt, int n_copi
     if (hipStreamCreate(&s) != hipSuccess) return -1.f;
     const size_t wbytes = (size_t)N * K * 2;
     const int Mreal = M;
-    M = (M + 63) / 64 * 64;  // allocation padding; the launch uses Mreal rows
+    M = (M + 127) / 128 * 128;  // allocation padding; the launch uses Mreal rows
     DBuf dW, dx, dh, dssq, dg, dy, dso, dact;
     if (!dW.alloc(wbytes * n_copies)) return -1.f;
     hipMemset(dW.p, 0x11, wbytes * n_copies);

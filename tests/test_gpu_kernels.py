@@ -37,7 +37,7 @@ def _norm_fold(h, gamma, eps):
     return ((h * gamma) * np.float32(0.0625)).astype(np.float16), (inv * 16.0).astype(np.float32)
 
 
-@pytest.mark.parametrize("M", [1, 3, 16, 17, 32, 45, 64, 100])
+@pytest.mark.parametrize("M", [1, 3, 16, 17, 32, 45, 64, 100, 129, 300])
 @pytest.mark.parametrize("N,K", [(4096, 1024), (1024, 2048), (1024, 3072), (3072, 1024)])
 def test_linear_store_f16(test_lib, M, N, K):
     rng = np.random.default_rng(M * 131 + N + K)
@@ -56,7 +56,7 @@ def test_linear_store_f16(test_lib, M, N, K):
         np.testing.assert_allclose(ssq, ref_ssq, rtol=1e-4)
 
 
-@pytest.mark.parametrize("M", [1, 7, 16, 32, 40])
+@pytest.mark.parametrize("M", [1, 7, 16, 32, 40, 65, 128, 200, 971])
 def test_linear_norm_prologue_and_swiglu(test_lib, M):
     rng = np.random.default_rng(900 + M)
     K, F = 1024, 3072
