@@ -22,8 +22,12 @@ struct CpFrameIO {
     const int* forced = nullptr;                   // teacher forcing (tests): see TalkerSampleArgs
 };
 
-// w.h / w.ssq hold the talker hidden of each row (position 0 input).  Runs positions 0..n_groups,
-// writes columns 1..n_groups of each row's frame.  Rows row0..row0+R-1 of a batch of R_total rows.
+// Runs positions 0..n_groups, writes columns 1..n_groups of each row's frame.  Rows row0..row0+R-1 of a batch of
+// R_total rows.  The talker hidden of row r (position 0's input) must sit in row cp_seed_row0(R, row0, R_total) + r
+// of w.h / w.ssq / w.xh: 0 in the sequential form (positions 0 and 1 as two passes), R16 = R rounded up to 16 in the
+// two-position form (one pass over 2 rows per utterance = the reference's --batch_prefill,
+// code_predictor_server.py:106-118, C++ default: code_predictor_server.cpp:257), which is used for whole batches.
+int cp_seed_row0(const Work& w, int R, int row0 = 0, int R_total = 0);
 int cp_frame(hipStream_t s, const Model& m, Work& w, KVCache& kv, int R, const CpFrameIO& io, int row0 = 0,
              int R_total = 0);
 

@@ -6,24 +6,69 @@
 
 namespace q3 {
 
+static bool two_row_enabled() {
+    static const bool on = !(getenv("Q3_CP_TWO_ROW") && atoi(getenv("Q3_CP_TWO_ROW")) == 0);
+    return on;
+}
+
+int cp_seed_row0(const Work& w, int R, int row0, int R_total) {
+    if (R_total <= 0) R_total = R;
+    const int R16 = (R + 15) / 16 * 16;
+    const bool two = two_row_enabled() && row0 == 0 && R_total == R && 2 * R16 <= w.max_rows;
+    return two ? R16 : 0;
+}
+
 int cp_frame(hipStream_t s, const Model& m, Work& w, KVCache& kv, int R, const CpFrameIO& io, int row0, int R_total) {
     const ModelCfg& c = m.cfg;
     if (R_total <= 0) R_total = R;
     const int H = c.hidden, G = c.cp_groups;
+    const int seed0 = cp_seed_row0(w, R, row0, R_total);
     RowMap rm;
     rm.slot_base = 0;
     rm.slot_stride = 1;  // row r owns KV slot r
     rm.pos_stride = 0;
-    // position 0: the talker hidden (code_predictor_server.py:121-122)
-    rm.pos_base = 0;
-    if (run_stack(s, m, m.cp, w, kv, R, rm, 256, row0)) return -1;
-    // position 1: TALKER codec embedding of code_0 (:97-98,123-124)
-    if (launch_gather_embed(s, m.talker_emb, c.talker_vocab, H, io.codes, 0, io.n_frames, io.frame_cap, 0, w.h, w.ssq, R,
-                            row0, R_total, io.forced, w.xh, m.cp.L[0].in_ln))
-        return -1;
-    for (int g = 0; g < G; g++) {
-        rm.pos_base = g + 1;
+    if (seed0 > 0) {
+        // positions 0 and 1 in ONE pass: rows [0, R) = position 1 (the TALKER codec embedding of code_0,
+        // code_predictor_server.py:97-98), rows [R16, R16 + R) = position 0 (the talker hidden); position 1 attends
+        // to both through the cache (prep, then attend).  What follows continues in rows [0, R).
+        const int R16 = seed0;
+        if (w.map_R16 != R16) {   // (first, eager call for this batch size; the captured replays find it ready)
+            std::vector<int> slot(2 * R16), pos(2 * R16);
+            for (int i = 0; i < 2 * R16; i++) {
+                slot[i] = i % R16;
+                pos[i] = i < R16 ? 1 : 0;
+            }
+            Q3_HIP(hipMemcpyAsync(w.map_slot, slot.data(), sizeof(int) * 2 * R16, hipMemcpyHostToDevice, s), -1);
+            Q3_HIP(hipMemcpyAsync(w.map_pos, pos.data(), sizeof(int) * 2 * R16, hipMemcpyHostToDevice, s), -1);
+            Q3_HIP(hipStreamSynchronize(s), -1);
+            w.map_R16 = R16;
+        }
+        if (launch_gather_embed(s, m.talker_emb, c.talker_vocab, H, io.codes, 0, io.n_frames, io.frame_cap, 0, w.h, w.ssq, R,
+                                row0, R_total, io.forced, w.xh, m.cp.L[0].in_ln))
+            return -1;
+        RowMap r2;
+        r2.slot = w.map_slot;
+        r2.pos = w.map_pos;
+        r2.same_slot_rows = true;
+        r2.valid_mod = R16;
+        r2.valid_n = R;
+        if (run_stack(s, m, m.cp, w, kv, R16 + R, r2, 256, 0)) return -1;
+    } else {
+        // position 0: the talker hidden (code_predictor_server.py:121-122)
+        rm.pos_base = 0;
         if (run_stack(s, m, m.cp, w, kv, R, rm, 256, row0)) return -1;
+        // position 1: TALKER codec embedding of code_0 (:97-98,123-124)
+        if (launch_gather_embed(s, m.talker_emb, c.talker_vocab, H, io.codes, 0, io.n_frames, io.frame_cap, 0, w.h, w.ssq, R,
+                                row0, R_total, io.forced, w.xh, m.cp.L[0].in_ln))
+            return -1;
+        rm.pos_base = 1;
+        if (run_stack(s, m, m.cp, w, kv, R, rm, 256, row0)) return -1;
+    }
+    for (int g = 0; g < G; g++) {
+        if (g > 0) {
+            rm.pos_base = g + 1;
+            if (run_stack(s, m, m.cp, w, kv, R, rm, 256, row0)) return -1;
+        }
         // final RMSNorm folded into the head GEMV's prologue (code_predictor_server.py:129,136)
         LinArgs a;
         a.wp = m.cp_head[g].wp;
@@ -113,7 +158,7 @@ void* cp_load(const char* weights, const char* embeddings_dir, int max_batch) {
     const ModelCfg& c = m->cfg;
     bool ok = hipStreamCreate(&h->s) == hipSuccess;
     ok = ok && kv_alloc(h->kv, c.cp_layers, max_batch, c.n_kv, c.cp_groups + 1) == 0;
-    ok = ok && work_alloc(h->w, c, max_batch, c.cp_ffn, c.cp_vocab) == 0;
+    ok = ok && work_alloc(h->w, c, 2 * ((max_batch + 15) / 16 * 16), c.cp_ffn, c.cp_vocab) == 0;   // two rows per utterance in the first pass
     ok = ok && hipMalloc((void**)&h->d_codes, sizeof(int) * 16 * max_batch) == hipSuccess;
     ok = ok && hipMalloc((void**)&h->d_nframes, sizeof(int) * max_batch) == hipSuccess;
     if (ok) {
@@ -169,7 +214,9 @@ int cp_predict_batch(void* hh, const float* hidden, const int32_t* code_0, int n
     io.top_k = top_k;
     io.seed = seed;
     auto body = [&]() -> int {
-        if (launch_ssq_rows(h->s, h->w.rows_in, h->w.h, h->w.ssq, R, H, h->w.xh, m.cp.L[0].in_ln)) return -1;
+        if (launch_ssq_rows(h->s, h->w.rows_in, h->w.h, h->w.ssq, R, H, h->w.xh, m.cp.L[0].in_ln,
+                            cp_seed_row0(h->w, R)))
+            return -1;
         return cp_frame(h->s, m, h->w, h->kv, R, io);
     };
     if (stochastic) {

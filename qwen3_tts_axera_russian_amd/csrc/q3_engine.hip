@@ -67,6 +67,7 @@ int talker_tail(Engine* e, hipStream_t st, int row0, int R) {
     f.out_copy_ssq = e->wc.ssq;
     f.out_copy_xh = e->wc.xh;
     f.out_copy_gamma = m.cp.L[0].in_ln;
+    f.out_copy_row_off = cp_seed_row0(e->wc, R, row0, e->B);   // where cp_frame expects its position-0 rows
     if (launch_final_norm(st, f)) return -1;
     LinArgs a;
     a.wp = m.talker_head.wp;
@@ -234,7 +235,7 @@ void* q3e_create(const char* weights, int max_batch, int n_ctx, int max_frames) 
     ok = ok && kv_alloc(e->kv_t, c.talker_layers, max_batch, c.n_kv, n_ctx) == 0;
     ok = ok && kv_alloc(e->kv_c, c.cp_layers, max_batch, c.n_kv, c.cp_groups + 1) == 0;
     ok = ok && work_alloc(e->wt, c, e->prefill_rows, c.talker_ffn, c.talker_vocab) == 0;
-    ok = ok && work_alloc(e->wc, c, max_batch, c.cp_ffn, c.cp_vocab) == 0;
+    ok = ok && work_alloc(e->wc, c, 2 * ((max_batch + 15) / 16 * 16), c.cp_ffn, c.cp_vocab) == 0;   // two rows per utterance in the CP's first pass
     auto ialloc = [&](int** p, size_t n) { return hipMalloc((void**)p, sizeof(int) * n) == hipSuccess; };
     ok = ok && ialloc(&e->d_slot, e->prefill_rows) && ialloc(&e->d_pos, e->prefill_rows);
     ok = ok && ialloc(&e->d_iota, max_batch) && ialloc(&e->d_past, (size_t)max_batch * 32);
@@ -398,6 +399,9 @@ int q3e_start(void* ee, int B, const float* prefix, const int32_t* n_rows, const
             f.out_copy_ssq = e->wc.ssq;
             f.out_copy_xh = e->wc.xh;
             f.out_copy_gamma = m.cp.L[0].in_ln;
+            // the first frame's code predictor pass reads its position-0 rows where cp_frame expects them; with
+            // parallel chains (rows split over several frame chains) that is the sequential layout, offset 0
+            f.out_copy_row_off = n_chains_eff(e) == 1 ? cp_seed_row0(e->wc, B, 0, B) : 0;
             if (launch_final_norm(e->s, f)) return -1;
         }
         Q3_HIP(hipStreamSynchronize(e->s), -1);  // host staging vectors are reused by the next group

@@ -67,6 +67,8 @@ struct AttnArgs {
     half_t* out = nullptr;  // [R][n_heads*128]
     float scale = 0.f;
     int threads = 256;
+    // rows r with (r % valid_mod) >= valid_n are padding (no slot of their own): skipped.  0 = every row is real.
+    int valid_mod = 0, valid_n = 0;
 };
 int launch_attn(hipStream_t s, const AttnArgs& a, int mode);
 
@@ -74,7 +76,7 @@ int launch_attn(hipStream_t s, const AttnArgs& a, int mode);
 // + ssq[m][p] = sum_{k in 16-block p} rows[m][k]^2  (H/16 partials per row)
 // + xh = fp16((rows*gamma)/16), the pre-scaled GEMM input of the layer whose norm weight is gamma (null: none)
 int launch_ssq_rows(hipStream_t s, const float* rows, float* h, float* ssq, int R, int H, half_t* xh = nullptr,
-                    const float* gamma = nullptr);
+                    const float* gamma = nullptr, int dst_row0 = 0);   // input row r lands in row dst_row0 + r
 
 // hidden = (h*inv)*gamma per row; optional outputs: f32 hidden, fp16 hidden,
 // a second f32 copy (+ its ssq partials) that seeds the code predictor.
@@ -92,6 +94,7 @@ struct FinalNormArgs {
     half_t* out_f16 = nullptr;
     float* out_copy = nullptr;
     float* out_copy_ssq = nullptr;
+    int out_copy_row_off = 0;                // the copy of output row r lands in row r + out_copy_row_off
     half_t* out_copy_xh = nullptr;           // pre-scaled GEMM input of the copy's consumer ...
     const float* out_copy_gamma = nullptr;   // ... whose norm weight this is
 };

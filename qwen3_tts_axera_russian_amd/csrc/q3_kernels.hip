@@ -615,14 +615,15 @@ __device__ __forceinline__ void store_row_ssq(float* h, float* ssq, int r, int H
 }
 
 __global__ void ssq_rows_kernel(const float* __restrict__ rows, float* __restrict__ h, float* __restrict__ ssq, int H,
-                                half_t* __restrict__ xh, const float* __restrict__ gamma) {
+                                half_t* __restrict__ xh, const float* __restrict__ gamma, int dst_row0) {
     const int r = blockIdx.x;
     for (int k4 = threadIdx.x; k4 < H / 4; k4 += blockDim.x)
-        store_row_ssq(h, ssq, r, H, k4, *(const float4*)(rows + (size_t)r * H + k4 * 4), xh, gamma);
+        store_row_ssq(h, ssq, dst_row0 + r, H, k4, *(const float4*)(rows + (size_t)r * H + k4 * 4), xh, gamma);
 }
-int launch_ssq_rows(hipStream_t s, const float* rows, float* h, float* ssq, int R, int H, half_t* xh, const float* gamma) {
+int launch_ssq_rows(hipStream_t s, const float* rows, float* h, float* ssq, int R, int H, half_t* xh, const float* gamma,
+                    int dst_row0) {
     if (R <= 0) return 0;
-    hipLaunchKernelGGL(ssq_rows_kernel, dim3(R), dim3(256), 0, s, rows, h, ssq, H, xh, gamma);
+    hipLaunchKernelGGL(ssq_rows_kernel, dim3(R), dim3(256), 0, s, rows, h, ssq, H, xh, gamma, dst_row0);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
 }
@@ -659,7 +660,8 @@ __global__ void final_norm_kernel(FinalNormArgs a) {
             p[2] = sat_half(o.z);
             p[3] = sat_half(o.w);
         }
-        if (a.out_copy) store_row_ssq(a.out_copy, a.out_copy_ssq, r, a.H, k4, o, a.out_copy_xh, a.out_copy_gamma);
+        if (a.out_copy)
+            store_row_ssq(a.out_copy, a.out_copy_ssq, r + a.out_copy_row_off, a.H, k4, o, a.out_copy_xh, a.out_copy_gamma);
     }
 }
 int launch_final_norm(hipStream_t s, const FinalNormArgs& a) {
@@ -722,6 +724,7 @@ __global__ void __launch_bounds__(1024) attn_kernel(AttnArgs a) {
     constexpr int D = 128;
     Q3_TL(30 + MODE);
     const int r = a.row0 + blockIdx.x, g = blockIdx.y;
+    if (a.valid_mod > 0 && (r % a.valid_mod) >= a.valid_n) return;   // padding row of a multi-position pass (block-uniform)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nwv = blockDim.x >> 6;
     const int slot = a.slot ? a.slot[r] : a.slot_base + r * a.slot_stride;

@@ -69,6 +69,10 @@ struct Work {
     float* hidden_f32 = nullptr;   // post-final-norm
     half_t* hidden_f16 = nullptr;
     float* logits = nullptr;       // [max_rows][max vocab]
+    // (slot, position) of the rows of the code predictor's two-position first pass (cp_frame): rows [0, R16) are
+    // position 1, rows [R16, 2*R16) position 0 of slots 0..R16-1; filled for map_R16
+    int *map_slot = nullptr, *map_pos = nullptr;
+    int map_R16 = 0;
 };
 int work_alloc(Work& w, const ModelCfg& c, int max_rows, int ffn, int max_vocab);
 void work_free(Work& w);
@@ -78,6 +82,7 @@ struct RowMap {            // which (slot, position) each row feeds
     const int* pos = nullptr;   // device [R] or null -> pos_base + r*pos_stride
     int slot_base = 0, slot_stride = 0, pos_base = 0, pos_stride = 0;
     bool same_slot_rows = false;  // rows depend on each other through the cache (prefill): split prep/attend
+    int valid_mod = 0, valid_n = 0;  // rows r with (r % valid_mod) >= valid_n are padding (AttnArgs)
 };
 
 // Run every layer of `st` over R rows whose residual stream (+ssq partials) sits in w.h / w.ssq.

@@ -277,10 +277,13 @@ int work_alloc(Work& w, const ModelCfg& c, int max_rows, int ffn, int max_vocab)
     Q3_HIP(hipMalloc((void**)&w.hidden_f16, R * c.hidden * 2), -1);
     Q3_HIP(hipMemset(w.hidden_f16, 0, R * c.hidden * 2), -1);
     Q3_HIP(hipMalloc((void**)&w.logits, R * max_vocab * 4), -1);
+    Q3_HIP(hipMalloc((void**)&w.map_slot, R * 4), -1);
+    Q3_HIP(hipMalloc((void**)&w.map_pos, R * 4), -1);
+    w.map_R16 = 0;
     return 0;
 }
 void work_free(Work& w) {
-    void* ps[] = {w.rows_in, w.h, w.ssq, w.xh, w.qkv, w.attn, w.act, w.hidden_f32, w.hidden_f16, w.logits};
+    void* ps[] = {w.rows_in, w.h, w.ssq, w.xh, w.qkv, w.attn, w.act, w.hidden_f32, w.hidden_f16, w.logits, w.map_slot, w.map_pos};
     for (void* p : ps)
         if (p) hipFree(p);
     w = Work();
@@ -342,6 +345,8 @@ int run_stack(hipStream_t s, const Model& m, const DevStack& st, Work& w, KVCach
         t.out = w.attn;
         t.scale = 1.0f / sqrtf((float)D);
         t.threads = attn_threads;
+        t.valid_mod = rm.valid_mod;
+        t.valid_n = rm.valid_n;
         if (rm.same_slot_rows && R > 1) {
             if (launch_attn(s, t, ATTN_PREP)) return -1;
             if (launch_attn(s, t, ATTN_ATTEND)) return -1;
