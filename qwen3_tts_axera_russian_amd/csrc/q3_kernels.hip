@@ -41,11 +41,12 @@ struct TlScope {
     }
 };
 __device__ unsigned long long* g_tl2 = nullptr;  // [nodes][TL2_MAXB][2] per-block start/end stamps
+__device__ int* g_tl2_kind = nullptr;             // [nodes] kernel kind id (the Q3_TL id) of each node
 constexpr int TL2_MAXB = 1024;
 struct TlScope2 {
     unsigned long long t0;
-    int node;
-    __device__ __forceinline__ TlScope2(int n) : node(n) { t0 = wall_clock64(); }
+    int node, kind;
+    __device__ __forceinline__ TlScope2(int n, int k) : node(n), kind(k) { t0 = wall_clock64(); }
     __device__ __forceinline__ ~TlScope2() {
         if (g_tl2 && node >= 0 && threadIdx.x == 0) {
             const unsigned b = blockIdx.x + gridDim.x * blockIdx.y;
@@ -53,12 +54,13 @@ struct TlScope2 {
                 g_tl2[((size_t)node * TL2_MAXB + b) * 2] = t0;
                 g_tl2[((size_t)node * TL2_MAXB + b) * 2 + 1] = wall_clock64();
             }
+            if (b == 0 && g_tl2_kind) g_tl2_kind[node] = kind;
         }
     }
 };
 #define Q3_TL(id)      \
     if (g_skip) return; \
-    TlScope2 tl_scope2_(a.tl_node); \
+    TlScope2 tl_scope2_(a.tl_node, id); \
     TlScope tl_scope_(id)
 #define Q3_PH(n)                                                                                       \
     do {                                                                                               \
@@ -1570,14 +1572,21 @@ namespace q3 {
 // host control of the diagnostic timeline
 static unsigned long long* g_ph_host = nullptr;
 static unsigned long long* g_tl2_host = nullptr;
+static int* g_tl2_kind_host = nullptr;
 static int g_tl_node_counter = -1;  // -1: numbering off
 int tl_next_node() { return g_tl_node_counter < 0 ? -1 : g_tl_node_counter++; }
 int tl2_begin(int max_nodes) {
     if (hipMalloc((void**)&g_tl2_host, (size_t)max_nodes * TL2_MAXB * 16) != hipSuccess) return -1;
     hipMemset(g_tl2_host, 0, (size_t)max_nodes * TL2_MAXB * 16);
     hipMemcpyToSymbol(HIP_SYMBOL(g_tl2), &g_tl2_host, sizeof(g_tl2_host));
+    if (hipMalloc((void**)&g_tl2_kind_host, (size_t)max_nodes * 4) != hipSuccess) return -1;
+    hipMemset(g_tl2_kind_host, 0xff, (size_t)max_nodes * 4);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_tl2_kind), &g_tl2_kind_host, sizeof(g_tl2_kind_host));
     g_tl_node_counter = 0;
     return 0;
+}
+int tl2_kinds(int* out, int max_nodes) {
+    return hipMemcpy(out, g_tl2_kind_host, (size_t)max_nodes * 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 int tl2_end(unsigned long long* out, int max_nodes) {
     hipDeviceSynchronize();
@@ -1619,6 +1628,7 @@ extern "C" int q3t_tl_begin(unsigned cap) { return q3::tl_begin(cap); }
 extern "C" int q3t_tl_end(unsigned long long* out, unsigned cap) { return q3::tl_end(out, cap); }
 extern "C" int q3t_tl2_begin(int max_nodes) { return q3::tl2_begin(max_nodes); }
 extern "C" int q3t_tl2_end(unsigned long long* out, int max_nodes) { return q3::tl2_end(out, max_nodes); }
+extern "C" int q3t_tl2_kinds(int* out, int max_nodes) { return q3::tl2_kinds(out, max_nodes); }
 extern "C" int q3t_tl_phases(unsigned long long* out, unsigned n) {
     return hipMemcpy(out, q3::g_ph_host, (size_t)n * 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
