@@ -81,11 +81,14 @@ def make_pack(cache, seed, rank, barrier):
     return path, cfg
 
 
-def make_voc_pack(cache, seed, rank, barrier):
+def make_voc_pack(cache, seed, rank, barrier, trunk_only=False):
+    """The whole decoder table (split RVQ, 8-layer sliding-window pre-transformer, x2 x2 upsamplers with ConvNeXt
+    blocks, BigVGAN-style trunk); trunk_only = round 1's timed table (the convolutional trunk alone)."""
     from qwen3_tts_axera_russian_amd import weights as W
-    path = os.path.join(cache, f"qwen3tts_voc_synth_s{seed}.q3w")
+    path = os.path.join(cache, f"qwen3tts_voc_{'trunk' if trunk_only else 'whole'}_s{seed}.q3w")
     if rank == 0 and not os.path.exists(path):
-        W.write_pack(path, {"voc_chunk": 64.0}, W.make_synthetic_voc(W.VocConfig(), seed=seed))
+        vc = W.trunk_voc_config() if trunk_only else W.VocConfig()
+        W.write_pack(path, {"voc_chunk": 64.0}, W.make_synthetic_voc(vc, seed=seed))
     barrier()
     return path
 
@@ -413,7 +416,9 @@ def main():
     }
     if voc is not None:
         fl = float(lib.voc_decode_flops(voc.h, B))
-        out["roofline_vocoder"] = {"kernel": "conv_kernel (exact-fp32 MFMA implicit-GEMM conv stack, whole chunk batch)",
+        out["roofline_vocoder"] = {"kernel": "conv_kernel (exact-fp32 MFMA implicit-GEMM convs) over the whole decoder table: RVQ, 8-layer "
+                                             "pre-transformer, x2 x2 upsamplers + ConvNeXt, BigVGAN trunk (hyper-parameters of the "
+                                             "transformer / ConvNeXt stages: recollection)",
                                    "bound": "mfma", "achieved": round(fl / (voc_ms * 1e-3) / 1e12, 2),
                                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": round(fl / (voc_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
@@ -427,6 +432,11 @@ def main():
             sp_ms = float(voc.ms[-1])
             dt_sp, _, _, _ = run_leg(eng, voc, prefixes, n_text, pad, F, 2, 1, sync_all)
             lib.voc_set_exact_fp32(1)
+            vt = Vocoder(lib, make_voc_pack(a.cache, a.seed, rank, barrier, trunk_only=True), B)
+            vt.decode(codes_alone.copy())
+            vt.decode(codes_alone.copy())
+            out["roofline_vocoder"]["trunk_only_avg_launch_ms"] = round(float(vt.ms[-1]), 3)   # without pre-transformer / ConvNeXt
+            vt.close()
             out["vocoder_split_f16x2"] = {"avg_launch_ms": round(sp_ms, 3),
                                           "achieved": round(3.0 * fl / (sp_ms * 1e-3) / 1e12, 2),
                                           "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -126,7 +126,7 @@ def test_full_size_table_is_causal_and_deterministic(gpu_lib, tmp_path_factory):
     vocoder): every convolution is causal, so the first 48 frames' samples must not change -- bit for bit --
     when the last 16 frames' codes do (what chunked streaming with overlap relies on, vocoder_server.py:84-117);
     a chunk decodes to the same samples alone and inside a batch; and twice the same input gives the same bits."""
-    path = os.path.join(CACHE, "voc_full_s1234.q3w")
+    path = os.path.join(CACHE, "voc_whole_s1234.q3w")
     if not os.path.exists(path):
         W.write_pack(path, {"voc_chunk": 64.0}, W.make_synthetic_voc(W.VocConfig(), seed=1234))
     v = Voc(gpu_lib, path, max_batch=3)
@@ -155,7 +155,7 @@ def test_full_size_table_matches_torch_reference_in_both_arithmetic_modes(gpu_li
     one 64-frame chunk against oracle/voc_ref.py (torch CPU fp32, ~1 s) in the exact-fp32 mode and in the
     2 x fp16 split-operand mode, tolerance 2e-4 of full scale (the waveform is clamped to [-1, 1]); plus the
     second chunk of a batch of two, so the batch index of the tiling is covered."""
-    path = os.path.join(CACHE, "voc_full_s1234.q3w")
+    path = os.path.join(CACHE, "voc_whole_s1234.q3w")
     if not os.path.exists(path):
         W.write_pack(path, {"voc_chunk": 64.0}, W.make_synthetic_voc(W.VocConfig(), seed=1234))
     _, tensors = W.read_pack(path)
@@ -174,6 +174,28 @@ def test_full_size_table_matches_torch_reference_in_both_arithmetic_modes(gpu_li
         assert err < 2e-4
         np.testing.assert_array_equal(one[0], out[1])
     gpu_lib.voc_set_exact_fp32(0)
+
+
+def test_decode_from_a_converted_speech_tokenizer_directory(gpu_lib, tmp_path):
+    """A speech_tokenizer/ directory (VOC_NAMES layout, layer scales as separate tensors) converted by
+    weights.convert_speech_tokenizer decodes to the waveform of the table it was exported from (2e-6: the layer
+    scales are divided out and folded back in f32)."""
+    vc = W.tiny_full_voc_config()
+    t = W.make_synthetic_voc(vc, seed=5)
+    a = str(tmp_path / "direct.q3w")
+    W.write_pack(a, {"voc_chunk": 64.0}, t)
+    W.export_speech_tokenizer_layout(t, vc, str(tmp_path / "speech_tokenizer"))
+    b = str(tmp_path / "converted.q3w")
+    vc2, report = W.convert_speech_tokenizer(str(tmp_path / "speech_tokenizer"), b)
+    print(report[0])
+    codes = np.random.default_rng(6).integers(0, 2048, size=(1, 64, 16)).astype(np.int64)
+    outs = []
+    for path in (a, b):
+        v = Voc(gpu_lib, path)
+        outs.append(v.decode(codes).copy())
+        v.close()
+    assert np.abs(outs[0]).max() > 1e-3
+    np.testing.assert_allclose(outs[1], outs[0], rtol=0, atol=2e-6)
 
 
 @pytest.fixture(scope="module")

@@ -34,6 +34,10 @@ def test_vocoder_program_shapes():
     assert sum(1 for r in prog if r[0] == W.VOP_CONVT) == 6
     # residual units: 4 blocks x 3 dilations
     assert sum(1 for r in prog if r[0] == W.VOP_CONV and r[5] & W.VF_RES_SAVE) == 12
+    # the default table is the whole decoder: 8 pre-transformer layers and a ConvNeXt block per x2 upsampler
+    assert sum(1 for r in prog if r[0] == W.VOP_ATTN) == 8 and sum(1 for r in prog if r[0] == W.VOP_DWCONV) == 2
+    trunk, _ = W.voc_program(W.trunk_voc_config())
+    assert len(trunk) == 34 and not any(r[0] in (W.VOP_ATTN, W.VOP_DWCONV, W.VOP_NORM, W.VOP_GLU) for r in trunk)
 
 
 def test_oracle_f16_rounding_matches_numpy():
