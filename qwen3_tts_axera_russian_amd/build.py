@@ -22,7 +22,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib")
 SOURCES = ["q3_common.cpp", "q3_formats.cpp", "q3_kernels.hip", "q3_model.hip", "q3_talker_api.hip", "q3_cp_api.hip",
-           "q3_engine.hip", "q3_voc.hip"]
+           "q3_engine.hip", "q3_voc.hip", "q3_text_api.hip"]
 TEST_SOURCES = ["q3_test_api.hip"]
 ARCH = os.environ.get("Q3_OFFLOAD_ARCH", "gfx950")
 # kernarg preload: the leading scalar kernel arguments arrive in SGPRs at wave launch (gfx940+)

@@ -534,10 +534,17 @@ bool Pack::add_safetensors(const char* path, std::string (*rename)(const std::st
 // A Q3TTSW1 container, or the reference's deployed files: `path` may be a container file, a
 // .safetensors / .npz / file, or a directory holding model.safetensors and/or
 // code_predictor_weights.npz; `aux_dir` (the servers' --embeddings_dir) adds codec_embedding.npy /
-// codec_head.npy.  Geometry (layer counts, vocabularies) is taken from what was found.
+// codec_head.npy and the text front-end's text_embedding / text_projection_* files.  Geometry (layer counts, vocabularies) is taken from what was found.
 bool Pack::open_auto(const char* path, const char* aux_dir) {
-    static const char* const kNpyTables[2][2] = {{"codec_embedding.npy", "talker.codec_embedding"},
-                                                 {"codec_head.npy", "talker.codec_head"}};
+    // the reference's embeddings/ directory (scripts/extract_embeddings.py:47-66; loaded by
+    // llamacpp_talker_server.py:79-93): codec tables + the text front-end's table and projection MLP
+    static const char* const kNpyTables[7][2] = {{"codec_embedding.npy", "talker.codec_embedding"},
+                                                 {"codec_head.npy", "talker.codec_head"},
+                                                 {"text_embedding.npy", "text.embedding"},
+                                                 {"text_projection_linear_fc1_weight.npy", "text.fc1.weight"},
+                                                 {"text_projection_linear_fc1_bias.npy", "text.fc1.bias"},
+                                                 {"text_projection_linear_fc2_weight.npy", "text.fc2.weight"},
+                                                 {"text_projection_linear_fc2_bias.npy", "text.fc2.bias"}};
     struct stat st;
     if (!path || stat(path, &st) != 0) {
         Q3_LOG("cannot open %s", path ? path : "(null)");

@@ -39,6 +39,9 @@ struct ConvArgs {
     int gelu = 0;                     // exact GELU applied to the input (ConvNeXt's second pointwise conv)
     int Cin = 0, M = 0, K = 0, dil = 1, Lin = 0, stride = 1, Cout = 0, clamp = 0;
     int n_tiles = 0, tiles_l = 0, tiles_m = 0;  // set by the launcher
+    // one-tap, stride-1 convs (pointwise projections): the columns of all B chunks form ONE axis of B*Lin columns
+    // (a column needs no neighbour), so 128-column tiles stay full when a chunk is only 64 columns long
+    int flat_B = 0;                              // > 0: flattened, B chunks
 };
 
 static int g_voc_split = 1;    // 1 (default): split-precision fp16 MFMA path where Cin % 16 == 0; 0: exact-fp32 MFMA everywhere
@@ -50,7 +53,7 @@ constexpr int VTN = 128;   // output columns per workgroup (4 waves x 32)
 // Staging goes global -> LDS directly; ~4 workgroups per CU hide its latency (a register-staged software
 // pipeline was tried: 199-256 VGPRs, one workgroup per SIMD, 1.6x slower at 32 chunks).
 template <int MT, int KT, int KC>
-__global__ void __launch_bounds__(256) conv_kernel(ConvArgs a) {
+__global__ void __launch_bounds__(256, MT >= 4 ? 3 : (MT == 3 ? 3 : 4)) conv_kernel(ConvArgs a) {
     constexpr int TM = 32 * MT, TMP = TM + 4, Q = KC / 4;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int halo = (KT - 1) * a.dil;
@@ -63,6 +66,7 @@ __global__ void __launch_bounds__(256) conv_kernel(ConvArgs a) {
         const int lx = tile % a.tiles_l, my = (tile / a.tiles_l) % a.tiles_m, b = tile / (a.tiles_l * a.tiles_m);
         const int l0 = lx * VTN, m0 = my * TM;
         const float* xb = a.x + (size_t)b * a.Cin * a.Lin;
+        const int Lcols = a.flat_B > 0 ? a.flat_B * a.Lin : a.Lin;   // columns of the tiled axis
         f16v acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
@@ -83,6 +87,30 @@ __global__ void __launch_bounds__(256) conv_kernel(ConvArgs a) {
                 *(float4*)(Ws + (k * KC + ci) * TMP + m4 * 4) = v;
             }
             // the input line buffer (causal: columns left of 0 are zero; Snake(0) = 0 so padding commutes)
+            if (KT == 1 && (a.Lin & 3) == 0) {
+                // one tap: no halo, the tile's 128 columns start 16-byte aligned -> 16-byte loads / ds_write_b128
+                for (int idx = tid; idx < KC * (VTN / 4); idx += 256) {
+                    const int ci = idx / (VTN / 4), c4 = (idx - ci * (VTN / 4)) * 4;
+                    const int gl = l0 + c4;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (gl < Lcols) {
+                        const int bb = a.flat_B > 0 ? gl / a.Lin : 0, l = gl - bb * a.Lin;   // (4 | Lin: a group stays in its chunk)
+                        v = *(const float4*)(xb + ((size_t)bb * a.Cin + ci0 + ci) * a.Lin + l);
+                        if (a.alpha) {
+                            const float al = a.alpha[ci0 + ci], ib = a.inv_beta[ci0 + ci];
+                            float sn;
+                            sn = __sinf(al * v.x); v.x = v.x + ib * (sn * sn);
+                            sn = __sinf(al * v.y); v.y = v.y + ib * (sn * sn);
+                            sn = __sinf(al * v.z); v.z = v.z + ib * (sn * sn);
+                            sn = __sinf(al * v.w); v.w = v.w + ib * (sn * sn);
+                        }
+                        if (a.gelu) {
+                            v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+                        }
+                    }
+                    *(float4*)(Xs + ci * XW + c4) = v;
+                }
+            } else
             for (int idx = tid; idx < KC * XW; idx += 256) {
                 const int ci = idx / XW, col = idx - ci * XW;
                 const int l = l0 - halo + col;
@@ -114,9 +142,11 @@ __global__ void __launch_bounds__(256) conv_kernel(ConvArgs a) {
             }
         }
         // epilogue.  D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-        const int l = l0 + w * 32 + (lane & 31);
+        const int gl = l0 + w * 32 + (lane & 31);
+        const int be = a.flat_B > 0 ? gl / a.Lin : b;
+        const int l = a.flat_B > 0 ? gl - be * a.Lin : gl;
         const int Lout = a.Lin * a.stride;
-        if (l < a.Lin) {
+        if (gl < Lcols) {
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -125,7 +155,7 @@ __global__ void __launch_bounds__(256) conv_kernel(ConvArgs a) {
                     if (m < a.M) {
                         const int co = a.stride == 1 ? m : m / a.stride;
                         const int p = a.stride == 1 ? 0 : m % a.stride;
-                        const size_t idx = ((size_t)b * a.Cout + co) * Lout + (size_t)l * a.stride + p;
+                        const size_t idx = ((size_t)be * a.Cout + co) * Lout + (size_t)l * a.stride + p;
                         float v = acc[mt][r];
                         if (a.bias) v += a.bias[co];
                         if (a.res) v += a.res[idx];
@@ -148,9 +178,10 @@ static int launch_conv_t(hipStream_t s, const ConvArgs& a, int B) {
     const size_t lds = ((size_t)KT * KC * TMP + (size_t)KC * (VTN + halo)) * sizeof(float);
     ConvArgs c = a;
     c.Mp = (a.M + 3) / 4 * 4;
-    c.tiles_l = (a.Lin + VTN - 1) / VTN;
+    c.flat_B = (KT == 1 && a.stride == 1 && (a.Lin & 3) == 0) ? B : 0;
+    c.tiles_l = ((c.flat_B > 0 ? a.Lin * B : a.Lin) + VTN - 1) / VTN;
     c.tiles_m = (a.M + TM - 1) / TM;
-    c.n_tiles = c.tiles_l * c.tiles_m * B;
+    c.n_tiles = c.tiles_l * c.tiles_m * (c.flat_B > 0 ? 1 : B);
     int grid = c.n_tiles;
     if (g_voc_max_wgs > 0 && grid > g_voc_max_wgs) grid = g_voc_max_wgs;
     hipLaunchKernelGGL((conv_kernel<MT, KT, KC>), dim3(grid), dim3(256), lds, s, c);
@@ -503,26 +534,41 @@ __global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ x
     y[((size_t)b * C + c) * L + l] = acc;
 }
 
-// RMSNorm (kind 0) / LayerNorm (kind 1) over the channels of every column
-__global__ void __launch_bounds__(256) chan_norm_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, float* __restrict__ y, int C, int L,
-                                                        int kind, float eps) {
-    const int l = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (l >= L) return;
-    const float* xc = x + (size_t)b * C * L + l;
+// RMSNorm (kind 0) / LayerNorm (kind 1) over the channels of every column.  Workgroup = 64 columns x 16 channel
+// lanes: a wave reads 64 consecutive columns of one channel (coalesced), the 16 partial sums of a column meet in LDS.
+// Two-pass variance (mean first), like the reference implementation.
+__global__ void __launch_bounds__(1024) chan_norm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int C, int L,
+                                                         int kind, float eps) {
+    __shared__ float part[16][64];
+    const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int l = blockIdx.x * 64 + col, b = blockIdx.y;
+    const bool ok = l < L;
+    const float* xc = x + (size_t)b * C * L + (ok ? l : 0);
+    auto column_sum = [&](float v) -> float {     // sum over the 16 channel lanes of a column, identical in all of them
+        part[g][col] = v;
+        __syncthreads();
+        float s_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) s_ += part[i][col];
+        __syncthreads();
+        return s_;
+    };
     float mu = 0.f;
     if (kind == 1) {
-        for (int c = 0; c < C; c++) mu += xc[(size_t)c * L];
-        mu /= (float)C;
+        float s_ = 0.f;
+        for (int c = g; c < C; c += 16) s_ += xc[(size_t)c * L];
+        mu = column_sum(s_) / (float)C;
     }
     float ss = 0.f;
-    for (int c = 0; c < C; c++) {
+    for (int c = g; c < C; c += 16) {
         const float d = xc[(size_t)c * L] - mu;
         ss += d * d;
     }
-    const float inv = 1.0f / sqrtf(ss / (float)C + eps);
+    const float inv = 1.0f / sqrtf(column_sum(ss) / (float)C + eps);
+    if (!ok) return;
     float* yc = y + (size_t)b * C * L + l;
-    for (int c = 0; c < C; c++) {
+    for (int c = g; c < C; c += 16) {
         float v = (xc[(size_t)c * L] - mu) * inv * w[c];
         if (bias) v += bias[c];
         yc[(size_t)c * L] = v;
@@ -577,6 +623,77 @@ __global__ void __launch_bounds__(64) voc_attn_kernel(const float* __restrict__ 
         float* yb = y + ((size_t)b * HD + h * D) * L;
         yb[(size_t)j * L + i] = o0 / lsum;
         yb[(size_t)(j + half) * L + i] = o1 / lsum;
+    }
+}
+
+// The same attention for a chunk whose q, k, v of one head fit in LDS (3 * L * D floats <= 64 KiB: the 64-column
+// chunks of the pre-transformer): one workgroup per (head, chunk) applies RoPE once per element while staging, then
+// every query is owned by 4 threads that split its keys 4 ways (online softmax each, merged by shuffles).
+__global__ void __launch_bounds__(256) voc_attn_tile_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int D,
+                                                            int L, int window, float theta) {
+    extern __shared__ float sm[];            // q[L][D+1] | k[L][D+1] | v[L][D+1]  (+1: conflict-free row walks)
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int half = D / 2, HD = H * D, DP = D + 1;
+    float *qs = sm, *ks = sm + (size_t)L * DP, *vs = sm + (size_t)2 * L * DP;
+    const float* xb = x + (size_t)b * 3 * HD * L;
+    // stage: element (d, l) of q / k rotated with its partner (d +- half, l); consecutive threads = consecutive l
+    for (int idx = tid; idx < half * L; idx += 256) {
+        const int j = idx / L, l = idx - j * L;
+        float sn, cs;
+        __sincosf((float)l * __powf(theta, -2.0f * (float)j / (float)D), &sn, &cs);
+#pragma unroll
+        for (int which = 0; which < 2; which++) {
+            const float* base = xb + (size_t)(which * HD + h * D) * L;
+            const float x0 = base[(size_t)j * L + l], x1 = base[(size_t)(j + half) * L + l];
+            float* dst = which == 0 ? qs : ks;
+            dst[l * DP + j] = x0 * cs - x1 * sn;
+            dst[l * DP + j + half] = x1 * cs + x0 * sn;
+        }
+    }
+    for (int idx = tid; idx < D * L; idx += 256) {
+        const int d = idx / L, l = idx - d * L;
+        vs[l * DP + d] = xb[(size_t)(2 * HD + h * D + d) * L + l];
+    }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)D);
+    for (int i0 = 0; i0 < L; i0 += 64) {       // 64 queries per round: thread = (query, key lane)
+        const int i = i0 + (tid >> 2), kl = tid & 3;
+        float m = -INFINITY, lsum = 0.f;
+        float o[64];                            // D <= 64 on this path
+#pragma unroll
+        for (int d = 0; d < 64; d++) o[d] = 0.f;
+        if (i < L) {
+            const int t0 = i - window + 1 > 0 ? i - window + 1 : 0;
+            for (int t = t0 + kl; t <= i; t += 4) {
+                float sc = 0.f;
+                for (int d = 0; d < D; d++) sc += qs[i * DP + d] * ks[t * DP + d];
+                sc *= scale;
+                const float mn = fmaxf(m, sc), corr = __expf(m - mn), pw = __expf(sc - mn);
+                lsum = lsum * corr + pw;
+#pragma unroll
+                for (int d = 0; d < 64; d++)
+                    if (d < D) o[d] = o[d] * corr + pw * vs[t * DP + d];
+                m = mn;
+            }
+        }
+        // merge the 4 key lanes of a query (lanes xor 1, 2); a lane that saw no key has m = -inf, l = 0
+#pragma unroll
+        for (int sft = 1; sft <= 2; sft <<= 1) {
+            const float om = __shfl_xor(m, sft, 64), ol = __shfl_xor(lsum, sft, 64);
+            const float mn = fmaxf(m, om);
+            const float c0 = m == -INFINITY ? 0.f : __expf(m - mn), c1 = om == -INFINITY ? 0.f : __expf(om - mn);
+            lsum = lsum * c0 + ol * c1;
+#pragma unroll
+            for (int d = 0; d < 64; d++) {
+                const float od = __shfl_xor(o[d], sft, 64);
+                o[d] = o[d] * c0 + od * c1;
+            }
+            m = mn;
+        }
+        if (i < L) {
+            float* yb = y + ((size_t)b * HD + h * D) * L + i;
+            for (int d = kl; d < D; d += 4) yb[(size_t)d * L] = o[d] / lsum;
+        }
     }
 }
 
@@ -1123,11 +1240,24 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
             if (op.op == VOP_DWCONV)
                 hipLaunchKernelGGL(dwconv_kernel, dim3(lb, op.cin, B), dim3(256), 0, v->s, in, op.w, op.bias, out, op.cin, (int)L, op.k);
             else if (op.op == VOP_NORM)
-                hipLaunchKernelGGL(chan_norm_kernel, dim3(lb, B), dim3(256), 0, v->s, in, op.w, op.bias, out, op.cin, (int)L,
+                hipLaunchKernelGGL(chan_norm_kernel, dim3((unsigned)((L + 63) / 64), B), dim3(1024), 0, v->s, in, op.w, op.bias, out, op.cin, (int)L,
                                    op.kind, op.eps);
-            else if (op.op == VOP_ATTN)
-                hipLaunchKernelGGL(voc_attn_kernel, dim3((unsigned)L, op.heads, B), dim3(64), 0, v->s, in, out, op.heads,
-                                   op.head_dim, (int)L, op.window, op.theta);
+            else if (op.op == VOP_ATTN) {
+                const size_t tile_lds = (size_t)3 * L * (op.head_dim + 1) * sizeof(float);
+                if (op.head_dim <= 64 && op.head_dim % 2 == 0 && tile_lds <= 64 * 1024) {
+                    static bool attr = false;
+                    if (!attr) {
+                        Q3_HIP(hipFuncSetAttribute((const void*)voc_attn_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   64 * 1024), -1);
+                        attr = true;
+                    }
+                    hipLaunchKernelGGL(voc_attn_tile_kernel, dim3(op.heads, B), dim3(256), tile_lds, v->s, in, out, op.heads,
+                                       op.head_dim, (int)L, op.window, op.theta);
+                } else {
+                    hipLaunchKernelGGL(voc_attn_kernel, dim3((unsigned)L, op.heads, B), dim3(64), 0, v->s, in, out, op.heads,
+                                       op.head_dim, (int)L, op.window, op.theta);
+                }
+            }
             else
                 hipLaunchKernelGGL(glu_kernel, dim3(lb, op.cout, B), dim3(256), 0, v->s, in, out, op.cout, (int)L, op.kind);
             Q3_HIP(hipGetLastError(), -1);

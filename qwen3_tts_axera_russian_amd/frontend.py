@@ -42,6 +42,47 @@ class TextFrontEnd:
         return out
 
 
+class DeviceTextFrontEnd:
+    """The same two calls on the GPU (include/qwen3tts_text.h): fp16 text table resident in HBM, fc1 / SiLU / fc2 and
+    the prefix assembly as device kernels.  Same attributes as TextFrontEnd (tts_pad_embed ...), so the talker server
+    takes either (--text_on_device)."""
+
+    def __init__(self, cfg, weights_path=None, embeddings_dir=None, max_tokens=2048):
+        from . import hiplib
+        self._hl, self._lib, self.cfg = hiplib, hiplib.load(), cfg
+        self.h = self._lib.tfe_load(str(weights_path).encode() if weights_path else None,
+                                    str(embeddings_dir).encode() if embeddings_dir else None, int(max_tokens))
+        if not self.h:
+            raise RuntimeError(f"tfe_load failed: {weights_path or embeddings_dir}")
+        self.hidden = self._lib.tfe_hidden_size(self.h)
+        c = cfg
+        self._special = np.array([c.im_start, c.assistant, c.newline, c.tts_pad, c.tts_bos, c.tts_eos, c.codec_pad, c.codec_bos,
+                                  c.codec_nothink, c.codec_think_bos, c.codec_think_eos, 0], np.int32)
+        sp = self.embed_text([c.tts_pad, c.tts_bos, c.tts_eos])
+        self.tts_pad_embed, self.tts_bos_embed, self.tts_eos_embed = sp[0], sp[1], sp[2]
+
+    def embed_text(self, token_ids):
+        ids = np.ascontiguousarray(token_ids, dtype=np.int32).reshape(-1)
+        out = np.empty((len(ids), self.hidden), np.float32)
+        if self._lib.tfe_embed_text(self.h, self._hl.iptr(ids), len(ids), self._hl.fptr(out)) != 0:
+            raise RuntimeError("tfe_embed_text failed")
+        return out
+
+    def build_prefix(self, text_token_ids, language="russian"):
+        ids = np.ascontiguousarray(text_token_ids, dtype=np.int32).reshape(-1)
+        out = np.empty((len(ids) + 9, self.hidden), np.float32)
+        n = self._lib.tfe_build_prefix(self.h, self._hl.iptr(ids) if len(ids) else None, len(ids),
+                                       self._hl.iptr(self._special), self._hl.fptr(out))
+        if n != len(ids) + 9:
+            raise RuntimeError(f"tfe_build_prefix failed: {n}")
+        return out
+
+    def destroy(self):
+        if self.h:
+            self._lib.tfe_free(self.h)
+            self.h = None
+
+
 class TalkerSampler:
     """Codec-token sampling with the reference's heuristics (llamacpp_talker_server.py:163-206): mask of
     ids 2048..2149 and >= 2151, adaptive EOS boost, repetition penalty over the set of the last 30

@@ -85,6 +85,14 @@ def load(path: str | None = None):
     _sig(lib, "voc_set_exact_fp32", c_int, [c_int])
     _sig(lib, "voc_last_decode_ms", c_float, [c_void_p])
     _sig(lib, "voc_decode_flops", ctypes.c_double, [c_void_p, c_int])
+    # include/qwen3tts_text.h
+    _sig(lib, "tfe_load", c_void_p, [c_char_p, c_char_p, c_int])
+    _sig(lib, "tfe_free", None, [c_void_p])
+    _sig(lib, "tfe_hidden_size", c_int, [c_void_p])
+    _sig(lib, "tfe_text_vocab", c_int, [c_void_p])
+    _sig(lib, "tfe_embed_text", c_int, [c_void_p, i32p, c_int, f32p])
+    _sig(lib, "tfe_build_prefix", c_int, [c_void_p, i32p, c_int, i32p, f32p])
+    _sig(lib, "tfe_tts_pad_embed", c_int, [c_void_p, f32p])
     _sig(lib, "q3_device_count", c_int, [])
     _sig(lib, "q3_set_device", c_int, [c_int])
     if path is None:

@@ -32,12 +32,17 @@ from .llama_cpp_bindings import LlamaCppModel
 class Qwen3TTSTalkerServer:
     def __init__(self, model_path, embeddings_dir=None, socket_path="/tmp/qwen3_talker.sock", temperature=0.8,
                  top_k=50, max_tokens=200, n_threads=4, kv_cache_dir="/tmp", tokenizer=None, n_ctx=512,
-                 install_signal_handlers=True):
+                 install_signal_handlers=True, text_on_device=False):
         self.socket_path, self.max_tokens, self.kv_cache_dir = socket_path, max_tokens, kv_cache_dir
         print("Loading embeddings...")
         # the reference's own embeddings/ directory (llamacpp_talker_server.py:79-93) or the container's text.* tensors
         self.cfg, self.front = load_text_front_end(model_path, embeddings_dir)
         self.codec_embedding = self.front.codec
+        if text_on_device:
+            # the text table (fp16) and the projection MLP live on the GPU (include/qwen3tts_text.h); the host copy
+            # above only supplied the configuration and the codec table the client-side code reads
+            from .frontend import DeviceTextFrontEnd
+            self.front = DeviceTextFrontEnd(self.cfg, None if embeddings_dir else model_path, embeddings_dir)
         self.tts_pad_embed = self.front.tts_pad_embed
         self.sampler = TalkerSampler(self.cfg.codec_eos, self.cfg.cp_vocab, temperature, top_k)
         self.tokenizer = None
@@ -180,9 +185,11 @@ def main():
     ap.add_argument("--kv_cache_dir", default="/tmp")
     ap.add_argument("--tokenizer", default=None, help="LOCAL tokenizer directory")
     ap.add_argument("--n_ctx", type=int, default=512)
+    ap.add_argument("--text_on_device", action="store_true",
+                    help="text table (fp16) + projection MLP + prefix assembly on the GPU instead of host numpy")
     a = ap.parse_args()
     Qwen3TTSTalkerServer(a.model, a.embeddings, a.socket, a.temperature, a.top_k, a.max_tokens, a.threads,
-                         a.kv_cache_dir, a.tokenizer, a.n_ctx).serve()
+                         a.kv_cache_dir, a.tokenizer, a.n_ctx, text_on_device=a.text_on_device).serve()
 
 
 if __name__ == "__main__":

@@ -18,10 +18,10 @@ def lib():
 def _declared(header):
     src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b((?:wrapper|cp|voc|q3e|q3)_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b((?:wrapper|cp|voc|q3e|q3|tfe)_[a-z0-9_]+)\s*\(", src)))
 
 
-@pytest.mark.parametrize("header", ["qwen3tts_talker.h", "qwen3tts_cp.h", "qwen3tts_voc.h", "qwen3tts_engine.h"])
+@pytest.mark.parametrize("header", ["qwen3tts_talker.h", "qwen3tts_cp.h", "qwen3tts_voc.h", "qwen3tts_engine.h", "qwen3tts_text.h"])
 def test_every_declared_symbol_is_exported(lib, header):
     names = _declared(header)
     assert len(names) >= 5
