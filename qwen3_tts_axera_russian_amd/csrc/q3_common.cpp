@@ -182,6 +182,26 @@ void ModelCfg::from_pack(const Pack& p) {
 
 }  // namespace q3
 
+namespace q3 {
+bool cu_partition_mask(bool complement, std::vector<uint32_t>& mask) {
+    const char* e = getenv("Q3_VOC_CUS");
+    const int n_voc = e ? atoi(e) : 0;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (n_voc <= 0 || hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    const int total = prop.multiProcessorCount;
+    if (n_voc >= total) return false;
+    mask.assign((total + 31) / 32, 0u);
+    for (int i = 0; i < n_voc; i++) {      // every k-th CU: each XCD / shader engine contributes equally
+        const int cu = (int)((long long)i * total / n_voc);
+        mask[cu / 32] |= 1u << (cu % 32);
+    }
+    if (complement)
+        for (int cu = 0; cu < total; cu++) mask[cu / 32] ^= 1u << (cu % 32);
+    return true;
+}
+}  // namespace q3
+
 // ---- device selection (include/qwen3tts_engine.h): one process per GPU ----
 extern "C" int q3_device_count(void) {
     int n = 0;

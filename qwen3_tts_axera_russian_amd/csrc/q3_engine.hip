@@ -220,7 +220,10 @@ void* q3e_create(const char* weights, int max_batch, int n_ctx, int max_frames) 
     int prio_lo = 0, prio_hi = 0;
     const bool use_prio = !(getenv("Q3_STREAM_PRIO") && atoi(getenv("Q3_STREAM_PRIO")) == 0) &&
                           hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess && prio_lo != prio_hi;
+    std::vector<uint32_t> cu_mask;   // Q3_VOC_CUS: the frame loop takes the CUs the vocoder's stream does not (q3_common.h)
+    const bool partition = cu_partition_mask(true, cu_mask);
     auto mkstream = [&](hipStream_t* st) {
+        if (partition) return hipExtStreamCreateWithCUMask(st, (uint32_t)cu_mask.size(), cu_mask.data()) == hipSuccess;
         return (use_prio ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_hi)
                          : hipStreamCreateWithFlags(st, hipStreamNonBlocking)) == hipSuccess;
     };

@@ -160,7 +160,10 @@ __global__ void __launch_bounds__(256, MT >= 4 ? 3 : (MT == 3 ? 3 : 4)) conv_ker
                         if (a.bias) v += a.bias[co];
                         if (a.res) v += a.res[idx];
                         if (a.clamp) v = fminf(fmaxf(v, -1.f), 1.f);
-                        a.y[idx] = v;
+                        // streaming store: activations are far larger than L2 and are read next by another launch; a
+                        // line left dirty in L2 is written back at the NEXT kernel boundary of any queue -- the frame
+                        // loop's, 553 times per frame, when the vocoder runs beside it
+                        __builtin_nontemporal_store(v, &a.y[idx]);
                     }
                 }
         }
@@ -838,18 +841,8 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
     // Q3_VOC_CUS=n: confine the vocoder's stream to n compute units, spread evenly over the XCDs (bit i of
     // the mask = CU i), so a concurrently running latency-bound frame loop keeps the others to itself.
     bool ok = true;
-    int n_cus = getenv("Q3_VOC_CUS") ? atoi(getenv("Q3_VOC_CUS")) : 0;
-    hipDeviceProp_t prop;
-    int dev = 0;
-    hipGetDevice(&dev);
-    if (n_cus > 0 && hipGetDeviceProperties(&prop, dev) == hipSuccess && n_cus < prop.multiProcessorCount) {
-        const int total = prop.multiProcessorCount;
-        std::vector<uint32_t> mask((total + 31) / 32, 0u);
-        // take every k-th CU so that each XCD / shader engine contributes equally
-        for (int i = 0; i < n_cus; i++) {
-            const int cu = (int)((long long)i * total / n_cus);
-            mask[cu / 32] |= 1u << (cu % 32);
-        }
+    std::vector<uint32_t> mask;
+    if (cu_partition_mask(false, mask)) {
         ok = hipExtStreamCreateWithCUMask(&v->s, (uint32_t)mask.size(), mask.data()) == hipSuccess;
         if (!ok) Q3_LOG("hipExtStreamCreateWithCUMask failed");
     } else {

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--exact", type=int, default=1)
     ap.add_argument("--full", type=int, default=1, help="0: the convolutional trunk alone")
+    ap.add_argument("--wgs", type=int, default=-1, help="voc_set_max_workgroups (persistent tile loop); -1 = library default")
     ap.add_argument("--cache", default=os.environ.get("Q3_BENCH_CACHE", "/tmp/q3_bench_cache"))
     a = ap.parse_args()
     from qwen3_tts_axera_russian_amd import hiplib
@@ -31,6 +32,8 @@ def main():
         W.write_pack(path, {"voc_chunk": 64.0}, W.make_synthetic_voc(vc, seed=1234))
     prog, _ = W.voc_program(vc)
     lib.voc_set_exact_fp32(a.exact)
+    if a.wgs >= 0:
+        lib.voc_set_max_workgroups(a.wgs)
     h = lib.voc_load(path.encode(), 64, a.batch)
     assert h
     B = a.batch
