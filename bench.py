@@ -212,25 +212,45 @@ def kv_bytes_per_step(n_text, frames, cfg):
     return sum(per_pos * t for t in t_avg) + cp * len(n_text)
 
 
-# HBM bytes per launch of the gate/up kernel from the PMC counters (profiles/r01_pmc_linear.md: FETCH_SIZE
+# HBM bytes per launch of the gate/up kernel from the PMC counters (profiles/r02_pmc_linear.md: FETCH_SIZE
 # doubled as the gfx950 guide prescribes + WRITE_SIZE), keyed by the row count it was collected at
-PMC_TRAFFIC_GATEUP = {32: 13.80e6 + 0.197e6, 1: 12.71e6 + 0.006e6}
+PMC_TRAFFIC_GATEUP = {32: 13.22e6 + 0.197e6, 1: 12.89e6 + 0.012e6}
 
 
-def dominant_kernel_roofline(lib, rows):
-    """The dominant kernel of the path by bytes: the fused RMSNorm -> gate/up GEMM -> SwiGLU launch
-    (12.58 MB of fp16 weights, 36 % of a layer's stream).  Timed live: back-to-back launches over 48
-    distinct weight copies (cold, like the layer walk), HIP events on the launch stream."""
-    import ctypes
-    from qwen3_tts_axera_russian_amd import hiplib
+def dominant_kernel_roofline(rows, cache):
+    """The dominant kernel of the path by bytes: the fused (RMSNorm-folded) gate/up GEMM -> SwiGLU launch (12.58 MB of
+    fp16 weights, 36 % of a layer's stream).  Its launch duration is measured IN the replayed frame graph -- the chain
+    the benchmark times, real activations -- by scripts/frame_timeline.py (child process, timeline build of the
+    library: device-clock stamps per workgroup, first entry -> last exit, mean over the 103 gate/up nodes of a frame;
+    the stamping lengthens a node by ~0.8 us, so the figure is conservative).  HIP events cannot bracket a node of a
+    graph replay and rocprofv3's kernel trace does not see inside one; the eager-mode rocprofv3 summary of the same
+    command is profiles/r02_bench_kernel_stats.csv.  Falls back to the stand-alone launch loop of the test library
+    (q3t_bench_linear) when the timeline library is not built."""
+    import subprocess
     N, K = 6144, 1024
-    us = float(hiplib.load_test().q3t_bench_linear(int(rows), N, K, 1, 2, 1, 48, 480))
-    algo = N * K * 2 + rows * K * 4 + rows * (N // 2) * 2      # weights + f32 activations in + fp16 out
+    algo = N * K * 2 + rows * K * 2 + rows * (N // 2) * 2      # weights + fp16 activations in + fp16 out
+    tl_lib = os.path.join(ROOT, "qwen3_tts_axera_russian_amd", "lib", "libqwen3tts_tl.so")
+    us, how, table = None, None, None
+    if os.path.exists(tl_lib):
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "frame_timeline.py"), "--json", "--batch",
+                                str(int(rows)), "--cache", cache], capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+            table = json.loads(line)
+            us = float(table["kinds"]["linear norm/swiglu (gate+up)"]["mean_span_us"])
+            how = "in-graph (replayed frame step), device-clock stamps per workgroup, timeline build; +~0.8 us stamping per node"
+        except Exception as e:      # noqa: BLE001 -- the measurement must not take the benchmark down
+            print(f"[bench] frame timeline failed ({e}); falling back to the stand-alone launch loop", file=sys.stderr)
+    if us is None:
+        from qwen3_tts_axera_russian_amd import hiplib
+        us = float(hiplib.load_test().q3t_bench_linear(int(rows), N, K, 1, 2, 1, 48, 480))
+        how = "stand-alone back-to-back launches over 48 weight copies (q3t_bench_linear), HIP events"
     ach = algo / (us * 1e-6) / 1e9
-    return {"kernel": "linear_kernel<gate/up+SwiGLU> (RMSNorm prologue, MFMA 16x16x32 f16, split-K over waves)",
-            "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC_GATEUP.get(int(rows)),
-            "algorithmic_bytes_per_launch": int(algo), "avg_launch_us": round(us, 3), "rows": int(rows)}
+    out = {"kernel": "linear_kernel<gate/up + SwiGLU> (RMSNorm folded, MFMA 16x16x32 f16, split-K over waves)",
+           "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC_GATEUP.get(int(rows)),
+           "algorithmic_bytes_per_launch": int(algo), "avg_launch_us": round(us, 3), "rows": int(rows), "measured": how}
+    return out, table
 
 
 def cpu_baseline(path, cfg, prefix, n_text, pad, frames, voc_path=None):
@@ -407,7 +427,7 @@ def main():
         "rtf": round((dt / a.steps) / (F * FRAME_SEC), 5),
         "rtf_aggregate": round((dt / a.steps) / (world * B * F * FRAME_SEC), 6),
         "prefill_ms": round(prefill_ms, 3), "vocoder_ms_per_step": round(voc_ms_step, 3),
-        "roofline": dominant_kernel_roofline(lib, B),
+        "roofline": None,
         "roofline_step": {"kernel": "frame-step hipGraph (talker 28L + 16 CP passes + heads, 560 nodes)",
                           "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
@@ -464,6 +484,11 @@ def main():
         out["cpu_baseline"] = cpu_baseline(path, cfg, prefixes[0], n_text[0], pad, a.cpu_frames,
                                            None if a.no_vocoder else make_voc_pack(a.cache, a.seed, rank, barrier))
     if rank == 0:
+        # the dominant kernel's in-graph launch duration (child process; this process's engines are gone by now)
+        out["roofline"], table = dominant_kernel_roofline(B, a.cache)
+        if table is not None:
+            out["frame_timeline"] = {k: {"n": v["n"], "span_us": v["mean_span_us"], "gap_us": v["mean_gap_before_us"]}
+                                     for k, v in table["kinds"].items()}
         print(json.dumps(out), flush=True)
     R.close()
 
