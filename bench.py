@@ -235,7 +235,10 @@ def dominant_kernel_roofline(rows, cache):
         try:
             r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "frame_timeline.py"), "--json", "--batch",
                                 str(int(rows)), "--cache", cache], capture_output=True, text=True, timeout=600)
-            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if not lines:
+                raise RuntimeError(f"no result line (rc {r.returncode}): {r.stderr[-400:]!r}")
+            line = lines[-1]
             table = json.loads(line)
             us = float(table["kinds"]["linear norm/swiglu (gate+up)"]["mean_span_us"])
             how = "in-graph (replayed frame step), device-clock stamps per workgroup, timeline build; +~0.8 us stamping per node"
@@ -428,7 +431,7 @@ def main():
         "rtf_aggregate": round((dt / a.steps) / (world * B * F * FRAME_SEC), 6),
         "prefill_ms": round(prefill_ms, 3), "vocoder_ms_per_step": round(voc_ms_step, 3),
         "roofline": None,
-        "roofline_step": {"kernel": "frame-step hipGraph (talker 28L + 16 CP passes + heads, 560 nodes)",
+        "roofline_step": {"kernel": "frame-step hipGraph (talker 28L + 15 code-predictor passes + heads, 553 nodes)",
                           "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                           "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(frame_ms, 4),

@@ -22,6 +22,7 @@ struct Engine {
     int prefill_rows = 0;
     // device state
     int *d_slot = nullptr, *d_pos = nullptr;       // prefill row maps [prefill_rows]
+    int* d_tiles = nullptr;                        // prefill attention tiles, int[4] each (<= prefill_rows of them)
     int *d_iota = nullptr;                         // [max_batch]
     int *d_past = nullptr, *d_npast = nullptr, *d_ntext = nullptr, *d_done = nullptr, *d_nframes = nullptr;
     int *d_pos0 = nullptr, *d_posdec = nullptr, *d_lastrow = nullptr;
@@ -182,7 +183,7 @@ void q3e_free(void* ee) {
     kv_free(e->kv_c);
     work_free(e->wt);
     work_free(e->wc);
-    void* ps[] = {e->d_slot, e->d_pos,  e->d_iota,   e->d_past,    e->d_npast, e->d_ntext, e->d_done,
+    void* ps[] = {e->d_tiles, e->d_slot, e->d_pos,  e->d_iota,   e->d_past,    e->d_npast, e->d_ntext, e->d_done,
                   e->d_nframes, e->d_pos0, e->d_posdec, e->d_lastrow, e->d_codes, e->d_pad, e->d_forced, e->d_seed};
     for (void* p : ps)
         if (p) hipFree(p);
@@ -241,6 +242,7 @@ void* q3e_create(const char* weights, int max_batch, int n_ctx, int max_frames) 
     ok = ok && work_alloc(e->wc, c, 2 * ((max_batch + 15) / 16 * 16), c.cp_ffn, c.cp_vocab) == 0;   // two rows per utterance in the CP's first pass
     auto ialloc = [&](int** p, size_t n) { return hipMalloc((void**)p, sizeof(int) * n) == hipSuccess; };
     ok = ok && ialloc(&e->d_slot, e->prefill_rows) && ialloc(&e->d_pos, e->prefill_rows);
+    ok = ok && ialloc(&e->d_tiles, (size_t)4 * e->prefill_rows);
     ok = ok && ialloc(&e->d_iota, max_batch) && ialloc(&e->d_past, (size_t)max_batch * 32);
     ok = ok && ialloc(&e->d_npast, max_batch) && ialloc(&e->d_ntext, max_batch) && ialloc(&e->d_done, max_batch);
     ok = ok && ialloc(&e->d_nframes, max_batch) && ialloc(&e->d_pos0, max_batch) && ialloc(&e->d_posdec, max_batch);
@@ -360,14 +362,20 @@ int q3e_start(void* ee, int B, const float* prefix, const int32_t* n_rows, const
     // the post-norm buffers, in utterance order, one group at a time.
     size_t row_off = 0;
     int b0 = 0;
-    std::vector<int> slot, pos;
+    std::vector<int> slot, pos, tiles;
     while (b0 < B) {
         int b1 = b0, rows = 0;
         while (b1 < B && rows + n_rows[b1] <= e->prefill_rows) rows += n_rows[b1++];
         slot.resize(rows);
         pos.resize(rows);
         int r = 0;
+        tiles.clear();
         for (int b = b0; b < b1; b++) {
+            for (int i = 0; i < n_rows[b]; i += 16) {      // the utterance's rows as runs of <= 16 positions (attn_tile_kernel)
+                const int n = n_rows[b] - i < 16 ? n_rows[b] - i : 16;
+                const int t4[4] = {r + i, n, b, i};
+                tiles.insert(tiles.end(), t4, t4 + 4);
+            }
             for (int i = 0; i < n_rows[b]; i++, r++) {
                 slot[r] = b;
                 pos[r] = i;
@@ -377,12 +385,15 @@ int q3e_start(void* ee, int B, const float* prefix, const int32_t* n_rows, const
         Q3_HIP(hipMemcpyAsync(e->wt.rows_in, prefix + row_off * H, sizeof(float) * (size_t)rows * H, hipMemcpyHostToDevice, e->s), -1);
         Q3_HIP(hipMemcpyAsync(e->d_slot, slot.data(), sizeof(int) * rows, hipMemcpyHostToDevice, e->s), -1);
         Q3_HIP(hipMemcpyAsync(e->d_pos, pos.data(), sizeof(int) * rows, hipMemcpyHostToDevice, e->s), -1);
+        Q3_HIP(hipMemcpyAsync(e->d_tiles, tiles.data(), sizeof(int) * tiles.size(), hipMemcpyHostToDevice, e->s), -1);
         Q3_HIP(hipMemcpyAsync(e->d_lastrow + b0, last.data() + b0, sizeof(int) * (b1 - b0), hipMemcpyHostToDevice, e->s), -1);
         if (launch_ssq_rows(e->s, e->wt.rows_in, e->wt.h, e->wt.ssq, rows, H, e->wt.xh, m.talker.L[0].in_ln)) return -1;
         RowMap rm;
         rm.slot = e->d_slot;
         rm.pos = e->d_pos;
         rm.same_slot_rows = true;
+        rm.tiles = e->d_tiles;
+        rm.n_tiles = (int)(tiles.size() / 4);
         if (run_stack(e->s, m, m.talker, e->wt, e->kv_t, rows, rm, 1024)) return -1;
         // final norm of the last rows of this group into rows b0..b1 of the post-norm buffers
         {

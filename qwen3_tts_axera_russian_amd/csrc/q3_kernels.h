@@ -69,6 +69,10 @@ struct AttnArgs {
     int threads = 256;
     // rows r with (r % valid_mod) >= valid_n are padding (no slot of their own): skipped.  0 = every row is real.
     int valid_mod = 0, valid_n = 0;
+    // ATTN_ATTEND over runs of consecutive positions of one slot (prefill): tiles[i] = {first row, rows (1..16), slot,
+    // position of the first row}; null with n_tiles > 0 = the rows row0.. are ONE run (slot_base, pos_base + i)
+    const int* tiles = nullptr;
+    int n_tiles = 0;
 };
 int launch_attn(hipStream_t s, const AttnArgs& a, int mode);
 

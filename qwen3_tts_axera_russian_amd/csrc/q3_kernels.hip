@@ -354,6 +354,69 @@ static int launch_linear_nt(hipStream_t s, const LinArgs& a) {
     return 0;
 }
 
+// Tile of a workgroup in the tiled GEMMs.  Workgroups are dealt to the 8 XCDs round-robin (linear id % 8), and every
+// XCD has its own L2: the R row tiles that share one weight column tile must sit on ONE XCD, or that tile is pulled
+// from HBM / Infinity Cache eight times (measured: the 971-row q/k/v GEMM moved ~80 MB for 8.4 MB of weights).
+// XCD x therefore owns column tiles x, x + 8, ...; its j-th workgroup is (row tile j % R, column tile x + 8 * (j / R)).
+__device__ __forceinline__ void gemm_tile_of_block(int R, int T, int& row_tile, int& col_tile) {
+    const int L = blockIdx.x;
+    if (T % 8 == 0) {
+        const int x = L & 7, j = L >> 3;
+        row_tile = j % R;
+        col_tile = x + 8 * (j / R);
+    } else {
+        row_tile = L % R;
+        col_tile = L / R;
+    }
+}
+
+// epilogue shared by the tiled GEMM kernels, straight from the accumulators
+template <int BM, int BN, int PRO, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const LinArgs& a, f4 (&acc)[BM / 32][BN / 32], const float* post, int m0,
+                                              int tile0, int wm, int wn, int q, int c) {
+    constexpr int WM = BM / 32, WN = BN / 32;
+    // ---- epilogue straight from the accumulators.  D layout: column = lane & 15, row = 4 * (lane >> 4) + reg ----
+#pragma unroll
+    for (int i = 0; i < WM; i++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int mr = (wm * WM + i) * 16 + 4 * q + r;
+            const int m = m0 + mr;
+            const bool ok = m < a.M;
+            const float ps = PRO == PRO_NORM ? post[mr] : 1.0f;
+            if (EPI == EPI_SWIGLU) {
+#pragma unroll
+                for (int j = 0; j < WN; j += 2) {
+                    const float g = acc[i][j][r] * ps, u = acc[i][j + 1][r] * ps;
+                    const float sg = __fdividef(g, 1.0f + __expf(-g));
+                    const int jn = ((tile0 + wn * WN + j) >> 1) * 16 + c;     // column of act[M][N/2]
+                    if (ok) a.act[frag_idx(m, jn, a.N / 2)] = sat_half(sg * u);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < WN; j++) {
+                    const int ng = (tile0 + wn * WN + j) * 16 + c;
+                    const float v = acc[i][j][r] * ps;
+                    if (EPI == EPI_STORE) {
+                        if (ok) a.y[(size_t)m * a.ldy + ng] = v;
+                    } else {
+                        const size_t hi = frag_idx(m, ng, a.N);
+                        const float hn = ok ? a.h_out[hi] + v : 0.f;
+                        if (ok) a.h_out[hi] = hn;
+                        if (ok && a.xh_out) a.xh_out[hi] = pre_scaled(hn, a.gamma[ng]);
+                        float s2 = hn * hn;
+                        s2 += __shfl_xor(s2, 8, 16);
+                        s2 += __shfl_xor(s2, 4, 16);
+                        s2 += __shfl_xor(s2, 2, 16);
+                        s2 += __shfl_xor(s2, 1, 16);
+                        if (ok && c == 0) a.ssq_out[(size_t)m * (a.N / 16) + (ng >> 4)] = s2;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // gemm_kernel<BM, BN, PRO, EPI> -- the same linear layers for MANY rows (prefill: llama_wrapper.c:125-163 with
 // n_tokens = n_text + 9, all utterances of a batch in one ragged pass).  A real tiled GEMM: workgroup = 4 waves
@@ -375,8 +438,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(LinArgs a) {
     Q3_TL(20 + PRO * 4 + EPI);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w >> 1, wn = w & 1, q = lane >> 4, c = lane & 15;
-    const int m0 = a.m_begin + blockIdx.x * BM;                 // row tile = fast grid index: the workgroups sharing a
-    const int tile0 = blockIdx.y * RB;                          // weight tile run together, it is streamed from HBM once
+    int row_tile, col_tile;
+    gemm_tile_of_block((a.M - a.m_begin + BM - 1) / BM, a.N / BN, row_tile, col_tile);
+    const int m0 = a.m_begin + row_tile * BM;
+    const int tile0 = col_tile * RB;
     const int KB = a.K >> 5, NST = KB / KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     h8* lds = (h8*)smem;                                        // [2][NF][64] fragments
@@ -443,47 +508,137 @@ __global__ void __launch_bounds__(256) gemm_kernel(LinArgs a) {
         }
         __syncthreads();
     }
-    // ---- epilogue straight from the accumulators.  D layout: column = lane & 15, row = 4 * (lane >> 4) + reg ----
+    gemm_epilogue<BM, BN, PRO, EPI>(a, acc, post, m0, tile0, wm, wn, q, c);
+}
+
+// ---------------------------------------------------------------------------
+// gemm_glds_kernel<BM, BN, PRO, EPI> -- the same tile GEMM with its operand stream as LDS-DMA
+// (global_load_lds_dwordx4: global -> LDS with no VGPR hop) into a ring of NBUF stage buffers, PF stages in flight.
+// A stage of gemm_kernel is bounded by the latency of its own loads (~2000 cycles against ~250 cycles of MFMA work
+// per 64 k): with M ~ 1000 rows the grid is one workgroup per CU, nothing else hides it.  Here three stages
+// (96 KiB per CU for the 128 x 128 tile) are always in flight; a wave waits only for ITS OWN pieces of the stage it
+// is about to read (counted s_waitcnt vmcnt), then one raw s_barrier makes the other waves' pieces visible.  The
+// fragment order of both operands in global memory is already the lane-linear 1 KiB image LDS-DMA writes.
+// ---------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int NBUF, int PRO, int EPI>
+__global__ void __launch_bounds__(512) gemm_glds_kernel(LinArgs a) {
+    // 8 waves: two groups of 4 (2 x 2 over the tile).  A stage holds KS = 2 k-blocks (64 k); group g multiplies
+    // k-block g of every stage, so each SIMD carries two waves whose LDS reads and MFMAs interleave (with one wave
+    // per SIMD they alternate: the tile ran at ~2800 cycles per stage against 512 of MFMA work).  The two groups'
+    // accumulators meet once, through LDS, in a fixed order (even k-blocks + odd k-blocks).
+    constexpr int RA = BM / 16, RB = BN / 16, KS = 2;           // fragments of the tile; k-blocks (32 k) per stage
+    constexpr int NF = (RA + RB) * KS, FPW = NF / 8;            // fragments per stage; per wave to fetch
+    constexpr int WM = BM / 32, WN = BN / 32;
+    constexpr int PF = NBUF - 1;                                // ring size NBUF; stages in flight
+    static_assert(NF % 8 == 0 && WN % 2 == 0, "tile shape");
+    static_assert((size_t)NBUF * NF * 1024 >= (size_t)4 * WM * WN * 4 * 64 * 4, "the ring must hold one group's accumulators");
+    Q3_TL(24 + PRO * 4 + EPI);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int grp = w >> 2, wq = w & 3;
+    const int wm = wq >> 1, wn = wq & 1, q = lane >> 4, c = lane & 15;
+    int row_tile, col_tile;
+    gemm_tile_of_block((a.M - a.m_begin + BM - 1) / BM, a.N / BN, row_tile, col_tile);
+    const int m0 = a.m_begin + row_tile * BM;
+    const int tile0 = col_tile * RB;
+    const int KB = a.K >> 5, NST = KB / KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // ONE LDS object: [NBUF][NF][64] fragments, then post[BM]
+    h8* lds = (h8*)smem;
+    float* post = (float*)(smem + (size_t)NBUF * NF * 1024);
+    const size_t arow = (size_t)(m0 >> 4) * KB;
+    auto issue = [&](int st) {       // this wave's FPW pieces of stage st -> ring buffer st % NBUF
+        h8* buf = lds + (size_t)(st % NBUF) * NF * 64;
+        const int kb0 = st * KS;
 #pragma unroll
-    for (int i = 0; i < WM; i++) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int mr = (wm * WM + i) * 16 + 4 * q + r;
-            const int m = m0 + mr;
-            const bool ok = m < a.M;
-            const float ps = PRO == PRO_NORM ? post[mr] : 1.0f;
-            if (EPI == EPI_SWIGLU) {
-#pragma unroll
-                for (int j = 0; j < WN; j += 2) {
-                    const float g = acc[i][j][r] * ps, u = acc[i][j + 1][r] * ps;
-                    const float sg = __fdividef(g, 1.0f + __expf(-g));
-                    const int jn = ((tile0 + wn * WN + j) >> 1) * 16 + c;     // column of act[M][N/2]
-                    if (ok) a.act[frag_idx(m, jn, a.N / 2)] = sat_half(sg * u);
-                }
+        for (int i = 0; i < FPW; i++) {
+            const int f = w * FPW + i;
+            const h8* src;
+            if (f < RA * KS) {
+                const int rb = f / KS, kk = f % KS;
+                src = (const h8*)(a.x16 + ((arow + (size_t)rb * KB + kb0 + kk) * 64 + lane) * 8);
             } else {
+                const int g = f - RA * KS, t = g / KS, kk = g % KS;
+                src = (const h8*)(a.wp + (((size_t)(tile0 + t) * KB + kb0 + kk) * 64 + lane) * 8);
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(buf + f * 64 + lane), 16, 0, 0);
+        }
+    };
+    // the norm scales first (ordinary loads: the compiler drains them with vmcnt(0) here, before any LDS-DMA exists)
+    if (PRO == PRO_NORM) {
+        for (int r = tid; r < BM; r += 512) {
+            const int m = m0 + r;
+            float sum = 0.f;
+            if (m < a.M) {
+                const float4* sp = (const float4*)(a.ssq + (size_t)m * 64);
 #pragma unroll
-                for (int j = 0; j < WN; j++) {
-                    const int ng = (tile0 + wn * WN + j) * 16 + c;
-                    const float v = acc[i][j][r] * ps;
-                    if (EPI == EPI_STORE) {
-                        if (ok) a.y[(size_t)m * a.ldy + ng] = v;
-                    } else {
-                        const size_t hi = frag_idx(m, ng, a.N);
-                        const float hn = ok ? a.h_out[hi] + v : 0.f;
-                        if (ok) a.h_out[hi] = hn;
-                        if (ok && a.xh_out) a.xh_out[hi] = pre_scaled(hn, a.gamma[ng]);
-                        float s2 = hn * hn;
-                        s2 += __shfl_xor(s2, 8, 16);
-                        s2 += __shfl_xor(s2, 4, 16);
-                        s2 += __shfl_xor(s2, 2, 16);
-                        s2 += __shfl_xor(s2, 1, 16);
-                        if (ok && c == 0) a.ssq_out[(size_t)m * (a.N / 16) + (ng >> 4)] = s2;
-                    }
+                for (int p = 0; p < 16; p++) {
+                    const float4 v = sp[p];
+                    sum += (v.x + v.y) + (v.z + v.w);
                 }
             }
+            post[r] = (1.0f / sqrtf(sum / (float)a.K + a.eps)) * NORM_POST;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int st = 0; st < PF; st++)
+        if (st < NST) issue(st);
+    f4 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < NST; ks++) {
+        // stages issued beyond ks at this point: min(PF - 1, NST - 1 - ks); wait until stage ks (mine) has landed
+        const int ahead = NST - 1 - ks;
+        if (ahead >= PF - 1) wait_vmcnt<(PF - 1) * FPW>();
+        else if (PF > 2 && ahead == 1) wait_vmcnt<FPW>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();          // everyone's pieces of stage ks are in LDS; everyone is done with stage ks - 1
+        asm volatile("" ::: "memory");
+        if (ks + PF < NST) issue(ks + PF);     // into the buffer stage ks - 1 occupied
+        const h8* cur = lds + (size_t)(ks % NBUF) * NF * 64;
+        h8 af[WM], bf[WN];
+#pragma unroll
+        for (int i = 0; i < WM; i++) af[i] = cur[((wm * WM + i) * KS + grp) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < WN; j++) bf[j] = cur[(RA * KS + (wn * WN + j) * KS + grp) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < WM; i++)
+#pragma unroll
+            for (int j = 0; j < WN; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    // ---- the odd k-blocks' accumulators (group 1) join the even ones (group 0) through the now idle ring ----
+    __builtin_amdgcn_s_barrier();              // every wave is done reading the last stage
+    asm volatile("" ::: "memory");
+    f4* xch = (f4*)smem;                       // [4 waves][WM * WN][64 lanes]
+    if (grp == 1) {
+#pragma unroll
+        for (int i = 0; i < WM; i++)
+#pragma unroll
+            for (int j = 0; j < WN; j++) xch[((size_t)wq * WM * WN + i * WN + j) * 64 + lane] = acc[i][j];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int i = 0; i < WM; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++) {
+            const f4 o = xch[((size_t)wq * WM * WN + i * WN + j) * 64 + lane];
+            acc[i][j] += o;
+        }
+    gemm_epilogue<BM, BN, PRO, EPI>(a, acc, post, m0, tile0, wm, wn, q, c);
 }
+
+// 1 (default): operand stream by LDS-DMA into a 4-stage ring (gemm_glds_kernel); 0: register-staged double buffer
+static int g_gemm_glds = getenv("Q3_GEMM_GLDS") ? atoi(getenv("Q3_GEMM_GLDS")) : 1;
+int set_gemm_glds(int on) { g_gemm_glds = on; return 0; }
 
 template <int BM, int BN, int PRO, int EPI>
 static int launch_gemm_t(hipStream_t s, const LinArgs& a) {
@@ -498,8 +653,20 @@ static int launch_gemm_t(hipStream_t s, const LinArgs& a) {
     }
     LinArgs b = a;
     b.tl_node = tl_next_node();
-    dim3 grid((a.M - a.m_begin + BM - 1) / BM, a.N / BN);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, KS, PRO, EPI>), grid, dim3(256), lds, s, b);
+    dim3 grid(((a.M - a.m_begin + BM - 1) / BM) * (a.N / BN));   // 1-D: the kernels map it to tiles XCD by XCD
+    if (g_gemm_glds) {
+        constexpr int NBUF = (BM + BN) > 256 ? 3 : 4;                                      // the ring must fit 160 KiB
+        constexpr size_t lds2 = (size_t)NBUF * ((BM + BN) / 16) * 2 * 1024 + BM * 4;       // ring + post[BM]
+        static bool attr2 = false;
+        if (!attr2) {
+            Q3_HIP(hipFuncSetAttribute((const void*)gemm_glds_kernel<BM, BN, NBUF, PRO, EPI>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2), -1);
+            attr2 = true;
+        }
+        hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, NBUF, PRO, EPI>), grid, dim3(512), lds2, s, b);
+    } else {
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, KS, PRO, EPI>), grid, dim3(256), lds, s, b);
+    }
     Q3_HIP(hipGetLastError(), -1);
     return 0;
 }
@@ -515,7 +682,12 @@ static int launch_gemm(hipStream_t s, const LinArgs& a, int pro, int epi) {
     }
     const bool narrow = a.N <= 2048;   // o / down (N = 1024): 64 x 64 tiles, else too few workgroups to fill 256 CUs
     if (pro == PRO_NORM && epi == EPI_STORE) return launch_gemm_t<128, 128, PRO_NORM, EPI_STORE>(s, a);
-    if (pro == PRO_NORM && epi == EPI_SWIGLU) return launch_gemm_t<128, 128, PRO_NORM, EPI_SWIGLU>(s, a);
+    if (pro == PRO_NORM && epi == EPI_SWIGLU) {
+        // gate/up, N = 6144: 192-column tiles = 32 x 8 = 256 workgroups for ~1000 rows, one per CU, one round
+        // (128-column tiles: 384 workgroups, two rounds)
+        if (g_gemm_glds && a.N % 192 == 0 && (a.N / 192) % 8 == 0) return launch_gemm_t<128, 192, PRO_NORM, EPI_SWIGLU>(s, a);
+        return launch_gemm_t<128, 128, PRO_NORM, EPI_SWIGLU>(s, a);
+    }
     if (pro == PRO_F16 && epi == EPI_RESID)
         return narrow ? launch_gemm_t<64, 64, PRO_F16, EPI_RESID>(s, a) : launch_gemm_t<128, 128, PRO_F16, EPI_RESID>(s, a);
     if (pro == PRO_F16 && epi == EPI_STORE)
@@ -1053,6 +1225,129 @@ __global__ void __launch_bounds__(256) attn_short_kernel(AttnArgs a) {
     a.out[frag_idx(r, (2 * g + hh) * D + d, a.n_heads * D)] = sat_half(o / L);
 }
 
+// ---------------------------------------------------------------------------
+// attn_tile_kernel -- the ATTEND step of a prefill for a tile of up to 16 consecutive positions of one utterance and
+// one kv head (2 q heads = 32 query rows).  The generic kernel spends one workgroup per (row, kv head): 7 768
+// workgroups of a microsecond each for the benchmark's 971-row prefill (30 us per layer).  Here the tile's queries
+// sit in LDS, the cache is walked in chunks of 64 positions staged once per chunk for all 32 query rows (K rows padded
+// to 272 B: conflict-free 16-B reads), every query row is owned by 8 lanes (keys 8 ways for the scores, 16-wide slices
+// of the head dimension for P.V), online softmax in f32, P.V in f32 on the fp16 V values: the same arithmetic as
+// attn_kernel, another summation order.  K/V of the tile's own positions are already in the cache (ATTN_PREP).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) attn_tile_kernel(AttnArgs a) {
+    constexpr int D = 128, KP = 136, CH = 64;       // head dim; padded K/V row (halfs); positions per chunk
+    Q3_TL(34);
+    const int g = blockIdx.y, tid = threadIdx.x;
+    int row0, nrows, slot, pos0;
+    if (a.tiles) {
+        const int4 t = *(const int4*)(a.tiles + 4 * blockIdx.x);
+        row0 = t.x; nrows = t.y; slot = t.z; pos0 = t.w;
+    } else {
+        row0 = a.row0 + blockIdx.x * 16;
+        nrows = a.R - blockIdx.x * 16 < 16 ? a.R - blockIdx.x * 16 : 16;
+        slot = a.slot_base;
+        pos0 = a.pos_base + blockIdx.x * 16;
+    }
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* qs = (float*)smem;                               // [32][D]  query rows: hh * 16 + i, pre-scaled
+    half_t* ks = (half_t*)(smem + 32 * D * 4);              // [CH][KP]
+    half_t* vs = ks + CH * KP;                              // [CH][KP]
+    float* ps = (float*)(vs + CH * KP);                     // [32][CH]
+    for (int idx = tid; idx < 32 * (D / 4); idx += 256) {
+        const int qr = idx / (D / 4), d4 = (idx - qr * (D / 4)) * 4, i = qr & 15, hh = qr >> 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < nrows) {
+            v = *(const float4*)(a.qkv + (size_t)(row0 + i) * a.ld + (size_t)(2 * g + hh) * D + d4);
+            v.x *= a.scale; v.y *= a.scale; v.z *= a.scale; v.w *= a.scale;
+        }
+        *(float4*)(qs + qr * D + d4) = v;
+    }
+    const size_t cbase = ((size_t)slot * a.n_kv + g) * (size_t)a.n_ctx * D;
+    const int qr = tid >> 3, kl = tid & 7;                  // query row of this thread; its key lane / output slice
+    const int qpos = pos0 + (qr & 15);
+    const bool qvalid = (qr & 15) < nrows;
+    const int T = pos0 + nrows;                             // cache positions 0 .. T-1 are visible to the tile
+    float m = -INFINITY, l = 0.f, o[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) o[j] = 0.f;
+    for (int c0 = 0; c0 < T; c0 += CH) {
+        __syncthreads();                                    // the previous chunk is consumed (first pass: qs is written)
+        for (int idx = tid; idx < CH * (D / 8); idx += 256) {
+            const int kr = idx / (D / 8), d8 = (idx - kr * (D / 8)) * 8;
+            h8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
+            if (c0 + kr < T) {
+                kv = *(const h8*)(a.kc + cbase + (size_t)(c0 + kr) * D + d8);
+                vv = *(const h8*)(a.vc + cbase + (size_t)(c0 + kr) * D + d8);
+            }
+            *(h8*)(ks + kr * KP + d8) = kv;
+            *(h8*)(vs + kr * KP + d8) = vv;
+        }
+        __syncthreads();
+        // scores of keys kl, kl + 8, ..., kl + 56 for query row qr
+        float sc[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) sc[j] = 0.f;
+        for (int d8 = 0; d8 < D; d8 += 8) {
+            const float4 q0 = *(const float4*)(qs + qr * D + d8), q1 = *(const float4*)(qs + qr * D + d8 + 4);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const h8 kk = *(const h8*)(ks + (kl + 8 * j) * KP + d8);
+                sc[j] += q0.x * (float)kk[0] + q0.y * (float)kk[1] + q0.z * (float)kk[2] + q0.w * (float)kk[3] +
+                         q1.x * (float)kk[4] + q1.y * (float)kk[5] + q1.z * (float)kk[6] + q1.w * (float)kk[7];
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (!(qvalid && c0 + kl + 8 * j <= qpos)) sc[j] = -INFINITY;      // causal mask (and rows beyond the tile)
+            mx = fmaxf(mx, sc[j]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 8));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 8));
+        mx = fmaxf(mx, __shfl_xor(mx, 4, 8));
+        const float mn = fmaxf(m, mx);
+        const float corr = (m == -INFINITY) ? 0.f : __expf(m - mn);           // (mn = -inf only for invalid rows)
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float pj = (sc[j] == -INFINITY) ? 0.f : __expf(sc[j] - mn);
+            ps[qr * CH + kl + 8 * j] = pj;
+            psum += pj;
+        }
+        psum += __shfl_xor(psum, 1, 8);
+        psum += __shfl_xor(psum, 2, 8);
+        psum += __shfl_xor(psum, 4, 8);
+        l = l * corr + psum;
+        m = mn;
+#pragma unroll
+        for (int j = 0; j < 16; j++) o[j] *= corr;
+        __syncthreads();                                    // the row's 64 probabilities are in LDS
+        const int nk = T - c0 < CH ? T - c0 : CH;
+        for (int kj = 0; kj < nk; kj++) {
+            const float pj = ps[qr * CH + kj];
+            const h8 v0 = *(const h8*)(vs + kj * KP + kl * 16), v1 = *(const h8*)(vs + kj * KP + kl * 16 + 8);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                o[j] += pj * (float)v0[j];
+                o[8 + j] += pj * (float)v1[j];
+            }
+        }
+    }
+    if (qvalid) {
+        const int r = row0 + (qr & 15), hh = qr >> 4;
+        const float inv = 1.0f / l;
+        half_t* dst = a.out + frag_idx(r, (2 * g + hh) * D + kl * 16, a.n_heads * D);   // 8-element groups stay contiguous
+        h8 w0, w1;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            w0[j] = sat_half(o[j] * inv);
+            w1[j] = sat_half(o[8 + j] * inv);
+        }
+        *(h8*)dst = w0;
+        *(h8*)(a.out + frag_idx(r, (2 * g + hh) * D + kl * 16 + 8, a.n_heads * D)) = w1;
+    }
+}
+
 int launch_attn(hipStream_t s, const AttnArgs& a, int mode) {
     if (a.R <= 0) return 0;
     if (a.n_heads != 2 * a.n_kv) {
@@ -1065,6 +1360,20 @@ int launch_attn(hipStream_t s, const AttnArgs& a, int mode) {
         AttnArgs a3 = a;
         a3.tl_node = tl_next_node();
         hipLaunchKernelGGL(attn_short_kernel, dim3(a.R, a.n_kv), dim3(256), 0, s, a3);
+        Q3_HIP(hipGetLastError(), -1);
+        return 0;
+    }
+    // prefill: runs of consecutive positions of one utterance -> 16-position tiles
+    if (mode == ATTN_ATTEND && a.n_tiles > 0) {
+        constexpr size_t lds = 32 * 128 * 4 + 2 * 64 * 136 * 2 + 32 * 64 * 4;
+        static bool attr = false;
+        if (!attr) {
+            Q3_HIP(hipFuncSetAttribute((const void*)attn_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), -1);
+            attr = true;
+        }
+        AttnArgs a4 = a;
+        a4.tl_node = tl_next_node();
+        hipLaunchKernelGGL(attn_tile_kernel, dim3(a.n_tiles, a.n_kv), dim3(256), lds, s, a4);
         Q3_HIP(hipGetLastError(), -1);
         return 0;
     }

@@ -83,6 +83,10 @@ struct RowMap {            // which (slot, position) each row feeds
     int slot_base = 0, slot_stride = 0, pos_base = 0, pos_stride = 0;
     bool same_slot_rows = false;  // rows depend on each other through the cache (prefill): split prep/attend
     int valid_mod = 0, valid_n = 0;  // rows r with (r % valid_mod) >= valid_n are padding (AttnArgs)
+    // same_slot_rows: the rows as runs of <= 16 consecutive positions of one slot (device int[4] per tile: first row,
+    // rows, slot, first position); without a table a pass with slot_stride 0 / pos_stride 1 is tiled implicitly
+    const int* tiles = nullptr;
+    int n_tiles = 0;
 };
 
 // Run every layer of `st` over R rows whose residual stream (+ssq partials) sits in w.h / w.ssq.

@@ -349,6 +349,13 @@ int run_stack(hipStream_t s, const Model& m, const DevStack& st, Work& w, KVCach
         t.valid_n = rm.valid_n;
         if (rm.same_slot_rows && R > 1) {
             if (launch_attn(s, t, ATTN_PREP)) return -1;
+            if (rm.tiles && rm.n_tiles > 0) {
+                t.tiles = rm.tiles;
+                t.n_tiles = rm.n_tiles;
+            } else if (!rm.slot && !rm.pos && rm.slot_stride == 0 && rm.pos_stride == 1 && rm.valid_mod == 0) {
+                t.tiles = nullptr;                  // one run of consecutive positions: tiled implicitly
+                t.n_tiles = (R + 15) / 16;
+            }
             if (launch_attn(s, t, ATTN_ATTEND)) return -1;
         } else {
             if (launch_attn(s, t, ATTN_FUSED)) return -1;

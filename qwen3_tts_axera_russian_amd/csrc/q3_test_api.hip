@@ -12,6 +12,7 @@ int set_linear_split_rows(int on);
 int set_linear_wide_tiles(int on);
 int set_attn_short(int on);
 int set_gemm_min_rows(int n);
+int set_gemm_glds(int on);
 }
 
 namespace {
@@ -33,6 +34,8 @@ int q3t_set_linear_wide_tiles(int on) { return set_linear_wide_tiles(on); }
 int q3t_set_attn_short(int on) { return set_attn_short(on); }
 // rows >= n take the tiled GEMM (gemm_kernel) instead of the weight-streaming kernel; default 65
 int q3t_set_gemm_min_rows(int n) { return set_gemm_min_rows(n); }
+// 1: LDS-DMA ring GEMM (default), 0: the register-staged double-buffer GEMM
+int q3t_set_gemm_glds(int on) { return set_gemm_glds(on); }
 
 // One linear launch.  W is row-major fp16 [N][K]; gateup != 0 means rows [0,N/2) are gate and
 // [N/2,N) up (tile-interleaved on the device like the model loader does).

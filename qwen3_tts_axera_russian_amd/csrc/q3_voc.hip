@@ -178,7 +178,18 @@ static int launch_conv_t(hipStream_t s, const ConvArgs& a, int B) {
         Q3_LOG("voc conv: dilation %d > 9 is not built", a.dil);
         return -1;
     }
-    const size_t lds = ((size_t)KT * KC * TMP + (size_t)KC * (VTN + halo)) * sizeof(float);
+    size_t lds = ((size_t)KT * KC * TMP + (size_t)KC * (VTN + halo)) * sizeof(float);
+    // experiment knob: Q3_VOC_LDS_PAD=bytes raises every conv launch's LDS request, i.e. lowers the vocoder's
+    // residency per CU evenly (room for the frame loop's workgroups when the two run side by side)
+    static const size_t lds_pad = getenv("Q3_VOC_LDS_PAD") ? (size_t)atol(getenv("Q3_VOC_LDS_PAD")) : 0;
+    if (lds_pad > lds) {
+        lds = lds_pad;
+        static bool attr = false;
+        if (!attr) {
+            Q3_HIP(hipFuncSetAttribute((const void*)conv_kernel<MT, KT, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), -1);
+            attr = true;
+        }
+    }
     ConvArgs c = a;
     c.Mp = (a.M + 3) / 4 * 4;
     c.flat_B = (KT == 1 && a.stride == 1 && (a.Lin & 3) == 0) ? B : 0;

@@ -118,6 +118,7 @@ def load_test():
     _sig(lib, "q3t_set_linear_wide_tiles", c_int, [c_int])
     _sig(lib, "q3t_set_attn_short", c_int, [c_int])
     _sig(lib, "q3t_set_gemm_min_rows", c_int, [c_int])
+    _sig(lib, "q3t_set_gemm_glds", c_int, [c_int])
     _sig(lib, "q3t_inspect_weights", c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, c_int])
     _sig(lib, "q3t_bench_linear", c_float, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int])
     _sig(lib, "q3t_bench_chain", c_float, [c_int, c_int, c_int, c_int, c_int, c_int])
