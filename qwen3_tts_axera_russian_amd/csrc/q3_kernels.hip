@@ -1226,126 +1226,212 @@ __global__ void __launch_bounds__(256) attn_short_kernel(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// attn_tile_kernel -- the ATTEND step of a prefill for a tile of up to 16 consecutive positions of one utterance and
-// one kv head (2 q heads = 32 query rows).  The generic kernel spends one workgroup per (row, kv head): 7 768
-// workgroups of a microsecond each for the benchmark's 971-row prefill (30 us per layer).  Here the tile's queries
-// sit in LDS, the cache is walked in chunks of 64 positions staged once per chunk for all 32 query rows (K rows padded
-// to 272 B: conflict-free 16-B reads), every query row is owned by 8 lanes (keys 8 ways for the scores, 16-wide slices
-// of the head dimension for P.V), online softmax in f32, P.V in f32 on the fp16 V values: the same arithmetic as
-// attn_kernel, another summation order.  K/V of the tile's own positions are already in the cache (ATTN_PREP).
+// attn_tile_mfma_kernel -- the ATTEND step of a prefill for a tile of up to 16 consecutive positions of one utterance
+// and one kv head (2 q heads = 32 query rows); K/V of the tile's own positions are already in the cache (ATTN_PREP).
+// The generic kernel spends one workgroup per (row, kv head): 7 768 workgroups of a microsecond each for the
+// benchmark's 971-row prefill, 30 us per layer.  Here both products run on the MFMA (v_mfma_f32_16x16x32_f16):
+// S = Q.K^T with K rows straight from the cache image (the B operand wants 8 consecutive head dims of one key: a K
+// row), O = P.V with V rows staged as they are and read through the hardware transposing LDS read
+// (ds_read_b64_tr_b16: a 16-lane group reads a 4 x 16 block and every lane receives one COLUMN of it -- the B operand
+// wants 8 consecutive keys of one head dim).  The contract keeps q and the softmax in f32: q and P are carried as two fp16 terms (hi,
+// lo = fp16((x - hi) * 2048)), two MFMAs per product, recombined in f32 -- 22 mantissa bits, the fp16 K / V values
+// exact.  Wave w owns keys 16w..16w+15 of a 64-key chunk for S and head dims 32w..32w+31 for O; row maxima and sums
+// meet through LDS; the O accumulators share S's row layout, so the online-softmax rescale needs no data movement.
+// Every global load of a chunk (and, for the first, the queries) is issued before anything waits.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) attn_tile_kernel(AttnArgs a) {
-    constexpr int D = 128, KP = 136, CH = 64;       // head dim; padded K/V row (halfs); positions per chunk
-    Q3_TL(34);
-    const int g = blockIdx.y, tid = threadIdx.x;
+__global__ void __launch_bounds__(256) attn_tile_mfma_kernel(AttnArgs a) {
+    constexpr int D = 128, QP = 136, VP = 72, CH = 64;
+    constexpr float LO = 2048.0f, ILO = 1.0f / 2048.0f;
+    Q3_TL(35);
+    const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c = lane & 15, q4 = lane >> 4;
     int row0, nrows, slot, pos0;
     if (a.tiles) {
         const int4 t = *(const int4*)(a.tiles + 4 * blockIdx.x);
         row0 = t.x; nrows = t.y; slot = t.z; pos0 = t.w;
-    } else {
+    } else {   // one run of consecutive positions of one slot
         row0 = a.row0 + blockIdx.x * 16;
         nrows = a.R - blockIdx.x * 16 < 16 ? a.R - blockIdx.x * 16 : 16;
         slot = a.slot_base;
         pos0 = a.pos_base + blockIdx.x * 16;
     }
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* qs = (float*)smem;                               // [32][D]  query rows: hh * 16 + i, pre-scaled
-    half_t* ks = (half_t*)(smem + 32 * D * 4);              // [CH][KP]
-    half_t* vs = ks + CH * KP;                              // [CH][KP]
-    float* ps = (float*)(vs + CH * KP);                     // [32][CH]
-    for (int idx = tid; idx < 32 * (D / 4); idx += 256) {
-        const int qr = idx / (D / 4), d4 = (idx - qr * (D / 4)) * 4, i = qr & 15, hh = qr >> 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < nrows) {
-            v = *(const float4*)(a.qkv + (size_t)(row0 + i) * a.ld + (size_t)(2 * g + hh) * D + d4);
-            v.x *= a.scale; v.y *= a.scale; v.z *= a.scale; v.w *= a.scale;
-        }
-        *(float4*)(qs + qr * D + d4) = v;
-    }
+    half_t* qh = (half_t*)smem;                 // [32][QP]   query rows: head * 16 + position, pre-scaled, hi term
+    half_t* ql = qh + 32 * QP;                  // [32][QP]   lo term
+    half_t* ks = ql + 32 * QP;                  // [CH][QP]   K rows of the chunk
+    half_t* vs = ks + CH * QP;                  // [CH][QP]   V rows of the chunk
+    half_t* ph = vs + CH * QP;                  // [32][VP]   P hi
+    half_t* pl = ph + 32 * VP;                  // [32][VP]   P lo
+    float* red = (float*)(pl + 32 * VP);        // [4][32] per-wave row maxima, then [4][32] row sums
+    float* red2 = red + 4 * 32;
     const size_t cbase = ((size_t)slot * a.n_kv + g) * (size_t)a.n_ctx * D;
-    const int qr = tid >> 3, kl = tid & 7;                  // query row of this thread; its key lane / output slice
-    const int qpos = pos0 + (qr & 15);
-    const bool qvalid = (qr & 15) < nrows;
-    const int T = pos0 + nrows;                             // cache positions 0 .. T-1 are visible to the tile
-    float m = -INFINITY, l = 0.f, o[16];
+    const int T = pos0 + nrows;
+    // K and V chunks: thread -> 4 pieces of 16 B each, rows idx / 16 (coalesced 256-B rows), zeros beyond T
+    h8 kreg[4], vreg[4];
+    auto load_chunk = [&](int c0) {
 #pragma unroll
-    for (int j = 0; j < 16; j++) o[j] = 0.f;
-    for (int c0 = 0; c0 < T; c0 += CH) {
-        __syncthreads();                                    // the previous chunk is consumed (first pass: qs is written)
-        for (int idx = tid; idx < CH * (D / 8); idx += 256) {
-            const int kr = idx / (D / 8), d8 = (idx - kr * (D / 8)) * 8;
-            h8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
+        for (int it = 0; it < 4; it++) {
+            const int idx = tid + it * 256, kr = idx >> 4, d8 = (idx & 15) * 8;
+            kreg[it] = vreg[it] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
             if (c0 + kr < T) {
-                kv = *(const h8*)(a.kc + cbase + (size_t)(c0 + kr) * D + d8);
-                vv = *(const h8*)(a.vc + cbase + (size_t)(c0 + kr) * D + d8);
+                kreg[it] = *(const h8*)(a.kc + cbase + (size_t)(c0 + kr) * D + d8);
+                vreg[it] = *(const h8*)(a.vc + cbase + (size_t)(c0 + kr) * D + d8);
             }
-            *(h8*)(ks + kr * KP + d8) = kv;
-            *(h8*)(vs + kr * KP + d8) = vv;
         }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int idx = tid + it * 256, kr = idx >> 4, d8 = (idx & 15) * 8;
+            *(h8*)(ks + kr * QP + d8) = kreg[it];
+            *(h8*)(vs + kr * QP + d8) = vreg[it];
+        }
+    };
+    load_chunk(0);          // in flight together with the query rows
+    for (int idx = tid; idx < 32 * (D / 8); idx += 256) {
+        const int qr = idx / (D / 8), d8 = (idx - qr * (D / 8)) * 8, i = qr & 15, hh = qr >> 4;
+        h8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = hi;
+        if (i < nrows) {
+            const float* src = a.qkv + (size_t)(row0 + i) * a.ld + (size_t)(2 * g + hh) * D + d8;
+            const float4 v0 = *(const float4*)src, v1 = *(const float4*)(src + 4);
+            const float e[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float x = e[j] * a.scale;
+                hi[j] = sat_half(x);
+                lo[j] = (half_t)((x - (float)hi[j]) * LO);
+            }
+        }
+        *(h8*)(qh + qr * QP + d8) = hi;
+        *(h8*)(ql + qr * QP + d8) = lo;
+    }
+    // rows this lane sees in every accumulator fragment: head qb, position 4 * q4 + r
+    float mrow[2][4], lrow[2][4];
+    f4 oh[2][2], ol[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            mrow[qb][r] = -INFINITY;
+            lrow[qb][r] = 0.f;
+        }
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) oh[qb][j] = ol[qb][j] = (f4){0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < T; c0 += CH) {
+        __syncthreads();                                    // previous chunk consumed
+        store_chunk();                                      // (keys beyond T are zeros; their P is exactly 0 anyway)
+        if (c0 + CH < T) load_chunk(c0 + CH);               // the next chunk travels under this chunk's products
         __syncthreads();
-        // scores of keys kl, kl + 8, ..., kl + 56 for query row qr
-        float sc[8];
+        // ---- S = Q.K^T for keys 16w .. 16w+15 of the chunk ----
+        f4 sh[2], sl[2];
+        sh[0] = sh[1] = sl[0] = sl[1] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 8; j++) sc[j] = 0.f;
-        for (int d8 = 0; d8 < D; d8 += 8) {
-            const float4 q0 = *(const float4*)(qs + qr * D + d8), q1 = *(const float4*)(qs + qr * D + d8 + 4);
+        for (int kb = 0; kb < 4; kb++) {
+            const h8 bk = *(const h8*)(ks + (16 * w + c) * QP + kb * 32 + q4 * 8);
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const h8 kk = *(const h8*)(ks + (kl + 8 * j) * KP + d8);
-                sc[j] += q0.x * (float)kk[0] + q0.y * (float)kk[1] + q0.z * (float)kk[2] + q0.w * (float)kk[3] +
-                         q1.x * (float)kk[4] + q1.y * (float)kk[5] + q1.z * (float)kk[6] + q1.w * (float)kk[7];
+            for (int qb = 0; qb < 2; qb++) {
+                const h8 ahi = *(const h8*)(qh + (16 * qb + c) * QP + kb * 32 + q4 * 8);
+                const h8 alo = *(const h8*)(ql + (16 * qb + c) * QP + kb * 32 + q4 * 8);
+                sh[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bk, sh[qb], 0, 0, 0);
+                sl[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bk, sl[qb], 0, 0, 0);
             }
         }
-        float mx = -INFINITY;
+        const int key = c0 + 16 * w + c;
+        float sc[2][4], mx[2][4];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (!(qvalid && c0 + kl + 8 * j <= qpos)) sc[j] = -INFINITY;      // causal mask (and rows beyond the tile)
-            mx = fmaxf(mx, sc[j]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 1, 8));
-        mx = fmaxf(mx, __shfl_xor(mx, 2, 8));
-        mx = fmaxf(mx, __shfl_xor(mx, 4, 8));
-        const float mn = fmaxf(m, mx);
-        const float corr = (m == -INFINITY) ? 0.f : __expf(m - mn);           // (mn = -inf only for invalid rows)
-        float psum = 0.f;
+        for (int qb = 0; qb < 2; qb++)
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const float pj = (sc[j] == -INFINITY) ? 0.f : __expf(sc[j] - mn);
-            ps[qr * CH + kl + 8 * j] = pj;
-            psum += pj;
-        }
-        psum += __shfl_xor(psum, 1, 8);
-        psum += __shfl_xor(psum, 2, 8);
-        psum += __shfl_xor(psum, 4, 8);
-        l = l * corr + psum;
-        m = mn;
+            for (int r = 0; r < 4; r++) {
+                const int i = 4 * q4 + r;
+                float v = sh[qb][r] + sl[qb][r] * ILO;
+                if (!(i < nrows && key <= pos0 + i)) v = -INFINITY;          // causal mask, rows beyond the tile
+                sc[qb][r] = v;
+                float x = v;
+                x = fmaxf(x, __shfl_xor(x, 1, 16));
+                x = fmaxf(x, __shfl_xor(x, 2, 16));
+                x = fmaxf(x, __shfl_xor(x, 4, 16));
+                x = fmaxf(x, __shfl_xor(x, 8, 16));
+                mx[qb][r] = x;
+                if (c == 0) red[w * 32 + 16 * qb + i] = x;
+            }
+        __syncthreads();
+        float corr[2][4];
 #pragma unroll
-        for (int j = 0; j < 16; j++) o[j] *= corr;
-        __syncthreads();                                    // the row's 64 probabilities are in LDS
-        const int nk = T - c0 < CH ? T - c0 : CH;
-        for (int kj = 0; kj < nk; kj++) {
-            const float pj = ps[qr * CH + kj];
-            const h8 v0 = *(const h8*)(vs + kj * KP + kl * 16), v1 = *(const h8*)(vs + kj * KP + kl * 16 + 8);
+        for (int qb = 0; qb < 2; qb++)
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                o[j] += pj * (float)v0[j];
-                o[8 + j] += pj * (float)v1[j];
+            for (int r = 0; r < 4; r++) {
+                const int qr = 16 * qb + 4 * q4 + r;
+                const float cm = fmaxf(fmaxf(red[qr], red[32 + qr]), fmaxf(red[64 + qr], red[96 + qr]));
+                const float mo = mrow[qb][r], mn = fmaxf(mo, cm);
+                corr[qb][r] = (mo == -INFINITY) ? 0.f : __expf(mo - mn);
+                const float p = (sc[qb][r] == -INFINITY) ? 0.f : __expf(sc[qb][r] - mn);
+                const half_t hi = (half_t)p;
+                ph[qr * VP + 16 * w + c] = hi;
+                pl[qr * VP + 16 * w + c] = (half_t)((p - (float)hi) * LO);
+                float ssum = p;
+                ssum += __shfl_xor(ssum, 1, 16);
+                ssum += __shfl_xor(ssum, 2, 16);
+                ssum += __shfl_xor(ssum, 4, 16);
+                ssum += __shfl_xor(ssum, 8, 16);
+                if (c == 0) red2[w * 32 + qr] = ssum;
+                mrow[qb][r] = mn;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int qb = 0; qb < 2; qb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int qr = 16 * qb + 4 * q4 + r;
+                lrow[qb][r] = lrow[qb][r] * corr[qb][r] + ((red2[qr] + red2[32 + qr]) + (red2[64 + qr] + red2[96 + qr]));
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    oh[qb][j][r] *= corr[qb][r];
+                    ol[qb][j][r] *= corr[qb][r];
+                }
+            }
+        // ---- O += P.V for head dims 32w .. 32w+31 ----
+#pragma unroll
+        for (int kst = 0; kst < 2; kst++) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                // B[k = 8 * q4 + e][column c] = V[key kst * 32 + 8 * q4 + e][head dim 32w + 16j + c]: lane 4q + p of a
+                // 16-lane group addresses row q, columns 4p .. 4p+3 of a 4 x 16 block and receives column (lane & 15)
+                typedef __fp16 hv4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+                const half_t* vb = vs + (kst * 32 + 8 * q4 + (c >> 2)) * QP + 32 * w + 16 * j + 4 * (c & 3);
+                const hv4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hv4*)vb);
+                const hv4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hv4*)(vb + 4 * QP));
+                h8 bv;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    bv[e] = (half_t)t0[e];
+                    bv[4 + e] = (half_t)t1[e];
+                }
+#pragma unroll
+                for (int qb = 0; qb < 2; qb++) {
+                    const h8 ahi = *(const h8*)(ph + (16 * qb + c) * VP + kst * 32 + q4 * 8);
+                    const h8 alo = *(const h8*)(pl + (16 * qb + c) * VP + kst * 32 + q4 * 8);
+                    oh[qb][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bv, oh[qb][j], 0, 0, 0);
+                    ol[qb][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bv, ol[qb][j], 0, 0, 0);
+                }
             }
         }
     }
-    if (qvalid) {
-        const int r = row0 + (qr & 15), hh = qr >> 4;
-        const float inv = 1.0f / l;
-        half_t* dst = a.out + frag_idx(r, (2 * g + hh) * D + kl * 16, a.n_heads * D);   // 8-element groups stay contiguous
-        h8 w0, w1;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            w0[j] = sat_half(o[j] * inv);
-            w1[j] = sat_half(o[8 + j] * inv);
+    for (int qb = 0; qb < 2; qb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int i = 4 * q4 + r;
+            if (i < nrows) {
+                const float inv = 1.0f / lrow[qb][r];
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const float o = (oh[qb][j][r] + ol[qb][j][r] * ILO) * inv;
+                    a.out[frag_idx(row0 + i, (2 * g + qb) * D + 32 * w + 16 * j + c, a.n_heads * D)] = sat_half(o);
+                }
+            }
         }
-        *(h8*)dst = w0;
-        *(h8*)(a.out + frag_idx(r, (2 * g + hh) * D + kl * 16 + 8, a.n_heads * D)) = w1;
-    }
 }
 
 int launch_attn(hipStream_t s, const AttnArgs& a, int mode) {
@@ -1364,16 +1450,17 @@ int launch_attn(hipStream_t s, const AttnArgs& a, int mode) {
         return 0;
     }
     // prefill: runs of consecutive positions of one utterance -> 16-position tiles
+    // prefill: runs of consecutive positions of one utterance -> 16-position tiles on the MFMA
     if (mode == ATTN_ATTEND && a.n_tiles > 0) {
-        constexpr size_t lds = 32 * 128 * 4 + 2 * 64 * 136 * 2 + 32 * 64 * 4;
+        constexpr size_t lds = (size_t)(2 * 32 * 136 + 2 * 64 * 136 + 2 * 32 * 72) * 2 + 8 * 32 * 4;
         static bool attr = false;
         if (!attr) {
-            Q3_HIP(hipFuncSetAttribute((const void*)attn_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), -1);
+            Q3_HIP(hipFuncSetAttribute((const void*)attn_tile_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), -1);
             attr = true;
         }
-        AttnArgs a4 = a;
-        a4.tl_node = tl_next_node();
-        hipLaunchKernelGGL(attn_tile_kernel, dim3(a.n_tiles, a.n_kv), dim3(256), lds, s, a4);
+        AttnArgs a5 = a;
+        a5.tl_node = tl_next_node();
+        hipLaunchKernelGGL(attn_tile_mfma_kernel, dim3(a.n_tiles, a.n_kv), dim3(256), lds, s, a5);
         Q3_HIP(hipGetLastError(), -1);
         return 0;
     }
