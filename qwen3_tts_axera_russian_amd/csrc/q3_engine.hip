@@ -127,7 +127,8 @@ int frame_chain(Engine* e, hipStream_t st, int row0, int R) {
     io.forced = e->forced_on ? e->d_forced : nullptr;
     if (cp_frame(st, m, e->wc, e->kv_c, R, io, row0, e->B)) return -1;
     RowMap rm;
-    rm.slot = e->d_iota;
+    rm.slot_base = 0;        // row r of the batch owns KV slot r (no table: one dependent load less in front of every attention)
+    rm.slot_stride = 1;
     rm.pos = e->d_posdec;
     if (run_stack(st, m, m.talker, e->wt, e->kv_t, R, rm, 1024, row0)) return -1;
     return talker_tail(e, st, row0, R);

@@ -71,6 +71,13 @@ struct TlScope2 {
 #define Q3_PH(n)
 #endif
 
+// Kernel arguments passed as one struct live in the kernarg segment and are fetched with scalar loads where the code
+// first needs them; behind control flow that becomes a CHAIN of s_load -> s_waitcnt round trips before the first
+// global load of a kernel is even issued (six of them in attn_kernel, seen in the ISA).  Naming the scalar fields in
+// one empty asm statement at the top makes the compiler fetch them all at once (adjacent fields merge into wide
+// loads) and wait once.
+#define Q3_FETCH_ARGS(...) asm volatile("" ::__VA_ARGS__)
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -191,10 +198,12 @@ __global__ void __launch_bounds__(NW * 64)
     if (PRO == PRO_NORM) {
 #pragma unroll
         for (int i = 0; i < SQI; i++) {
-            const int g4 = tid + i * NTH;          // float4 group: row = g4/16 (64 partials = 16 float4)
-            const int m = m0 + g4 / 16;
-            sq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g4 < MR * 16 && m < a.M) sq[i] = *(const float4*)(a.ssq + (size_t)m * 64 + (g4 & 15) * 4);
+            // float4 group: row = g4/16 (64 partials = 16 float4).  UNCONDITIONAL load (index clamped; rows beyond a.M are
+            // allocated padding of the row block): a predicated load becomes a branch, and the compiler sinks the first
+            // use of the loaded value -- with its s_waitcnt vmcnt(0) -- into that branch, ahead of the weight stream's
+            // issue: a whole dependent memory round trip in front of every normed GEMM (seen in the ISA, round 2)
+            const int g4 = tid + i * NTH, g4c = g4 < MR * 16 ? g4 : 0;
+            sq[i] = *(const float4*)(a.ssq + (size_t)(m0 + g4c / 16) * 64 + (g4c & 15) * 4);
         }
     }
     if (EPI == EPI_RESID) {
@@ -228,6 +237,10 @@ __global__ void __launch_bounds__(NW * 64)
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    // the epilogue's scalar arguments beyond the preloaded ones: fetched now, under the weight stream, not at the epilogue
+    if (EPI == EPI_RESID) Q3_FETCH_ARGS("s"(a.ssq_out), "s"(a.xh_out));
+    if (EPI == EPI_STORE) Q3_FETCH_ARGS("s"(a.ldy));
+    if (PRO == PRO_NORM) Q3_FETCH_ARGS("s"(a.eps));
     Q3_PH(0);  // all loads issued
 
     // ---- 2. RMSNorm scale per row from the producer's 64 sum-of-squares partials (a.ssq_parts == 64): only the
@@ -806,6 +819,9 @@ int launch_ssq_rows(hipStream_t s, const float* rows, float* h, float* ssq, int 
 // final RMSNorm of selected rows
 // ---------------------------------------------------------------------------
 __global__ void final_norm_kernel(FinalNormArgs a) {
+    Q3_FETCH_ARGS("s"(a.h), "s"(a.ssq), "s"(a.ssq_parts), "s"(a.gamma), "s"(a.eps), "s"(a.H), "s"(a.row0), "s"(a.row_map), "s"(a.src_off),
+                  "s"(a.out_f32), "s"(a.out_f16), "s"(a.out_copy), "s"(a.out_copy_ssq), "s"(a.out_copy_xh), "s"(a.out_copy_gamma),
+                  "s"(a.out_copy_row_off));
     Q3_TL(40);
     __shared__ float inv_sh;
     const int r = a.row0 + blockIdx.x;
@@ -896,6 +912,9 @@ int launch_gather_embed(hipStream_t s, const float* table, int V, int H, const i
 template <int MODE>
 __global__ void __launch_bounds__(1024) attn_kernel(AttnArgs a) {
     constexpr int D = 128;
+    Q3_FETCH_ARGS("s"(a.qkv), "s"(a.ld), "s"(a.row0), "s"(a.q_norm), "s"(a.k_norm), "s"(a.eps), "s"(a.rope_cos), "s"(a.rope_sin),
+                  "s"(a.slot), "s"(a.pos), "s"(a.slot_base), "s"(a.slot_stride), "s"(a.pos_base), "s"(a.pos_stride), "s"(a.kc),
+                  "s"(a.vc), "s"(a.n_ctx), "s"(a.n_kv), "s"(a.n_heads), "s"(a.out), "s"(a.scale), "s"(a.valid_mod), "s"(a.valid_n));
     Q3_TL(30 + MODE);
     const int r = a.row0 + blockIdx.x, g = blockIdx.y;
     if (a.valid_mod > 0 && (r % a.valid_mod) >= a.valid_n) return;   // padding row of a multi-position pass (block-uniform)
@@ -1113,6 +1132,9 @@ static int g_attn_short = 1;
 int set_attn_short(int on) { g_attn_short = on; return 0; }
 __global__ void __launch_bounds__(256) attn_short_kernel(AttnArgs a) {
     constexpr int D = 128, NE = ATTN_SHORT_MAX_T + 1;   // entries: <= 15 cached rows + the appended token
+    Q3_FETCH_ARGS("s"(a.qkv), "s"(a.ld), "s"(a.row0), "s"(a.q_norm), "s"(a.k_norm), "s"(a.eps), "s"(a.rope_cos), "s"(a.rope_sin),
+                  "s"(a.slot), "s"(a.slot_base), "s"(a.slot_stride), "s"(a.pos_base), "s"(a.kc), "s"(a.vc), "s"(a.n_ctx),
+                  "s"(a.n_kv), "s"(a.n_heads), "s"(a.out), "s"(a.scale));
     Q3_TL(33);
     const int r = a.row0 + blockIdx.x, g = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1834,6 +1856,9 @@ __device__ __forceinline__ void feedback_row(const int* codes, int r, const floa
 // One workgroup per row: the 2048 logits arrive as two float4 per thread (one round trip), one barrier
 // picks the winner, then the next embedding row is gathered (second round trip).
 __global__ void __launch_bounds__(256) cp_argmax_kernel(CpArgmaxArgs a) {
+    Q3_FETCH_ARGS("s"(a.logits), "s"(a.V), "s"(a.H), "s"(a.row0), "s"(a.R_total), "s"(a.R), "s"(a.group), "s"(a.codes), "s"(a.n_frames),
+                  "s"(a.frame_cap), "s"(a.next_table), "s"(a.h_out), "s"(a.ssq_out), "s"(a.xh_out), "s"(a.gamma_next),
+                  "s"(a.talker_emb), "s"(a.temperature), "s"(a.forced));
     Q3_TL(43);
     __shared__ float sv[4];
     __shared__ int si[4];
