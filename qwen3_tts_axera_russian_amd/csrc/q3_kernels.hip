@@ -78,6 +78,14 @@ struct TlScope2 {
 // loads) and wait once.
 #define Q3_FETCH_ARGS(...) asm volatile("" ::__VA_ARGS__)
 
+// A per-row scalar (position, slot, frame counter ...) that a previous kernel wrote and every lane of the workgroup
+// needs: read through the constant address space, i.e. with a SCALAR load (s_load_dword: straight into an SGPR, its
+// own counter, ~half the latency of a vector load, and the vector loads that follow are issued without waiting for
+// it).  Written by an earlier launch only, never by this one: the scalar cache is invalidated at every dispatch.
+__device__ __forceinline__ int uniform_load(const int* p) {
+    return *(const __attribute__((address_space(4))) int*)p;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -825,7 +833,7 @@ __global__ void final_norm_kernel(FinalNormArgs a) {
     Q3_TL(40);
     __shared__ float inv_sh;
     const int r = a.row0 + blockIdx.x;
-    const int src = a.row_map ? a.row_map[r] : r + a.src_off;
+    const int src = a.row_map ? uniform_load(a.row_map + r) : r + a.src_off;
     if (threadIdx.x < 64) {
         float s = 0.f;
         for (int p = threadIdx.x; p < a.ssq_parts; p += 64) s += a.ssq[(size_t)src * a.ssq_parts + p];
@@ -874,12 +882,12 @@ __global__ void gather_embed_kernel(const float* __restrict__ table, int V, int 
     const int r = row0 + blockIdx.x;
     int t;
     if (n_frames) {
-        int f = n_frames[r] - 1;
+        int f = uniform_load(n_frames + r) - 1;
         if (f < 0) f = 0;
         if (f >= frame_cap) f = frame_cap - 1;
-        t = tok[((size_t)f * R_total + r) * 16 + col];
+        t = uniform_load(tok + ((size_t)f * R_total + r) * 16 + col);
         if (forced) {   // teacher forcing (tests): continue with the forced id where one is given
-            const int fz = forced[((size_t)f * R_total + r) * 16 + col];
+            const int fz = uniform_load(forced + ((size_t)f * R_total + r) * 16 + col);
             if (fz >= 0 && t >= 0) t = fz;
         }
     } else {
@@ -920,8 +928,8 @@ __global__ void __launch_bounds__(1024) attn_kernel(AttnArgs a) {
     if (a.valid_mod > 0 && (r % a.valid_mod) >= a.valid_n) return;   // padding row of a multi-position pass (block-uniform)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nwv = blockDim.x >> 6;
-    const int slot = a.slot ? a.slot[r] : a.slot_base + r * a.slot_stride;
-    const int pos = a.pos ? a.pos[r] : a.pos_base + r * a.pos_stride;
+    const int slot = a.slot ? uniform_load(a.slot + r) : a.slot_base + r * a.slot_stride;
+    const int pos = a.pos ? uniform_load(a.pos + r) : a.pos_base + r * a.pos_stride;
     __shared__ float qs[2][D];
     __shared__ float knew[D], vnew[D];
     extern __shared__ __attribute__((aligned(16))) float dyn[];
@@ -1138,7 +1146,7 @@ __global__ void __launch_bounds__(256) attn_short_kernel(AttnArgs a) {
     Q3_TL(33);
     const int r = a.row0 + blockIdx.x, g = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int slot = a.slot ? a.slot[r] : a.slot_base + r * a.slot_stride;
+    const int slot = a.slot ? uniform_load(a.slot + r) : a.slot_base + r * a.slot_stride;
     const int T = a.pos_base;                       // cached rows = position of the appended token (row-uniform)
     __shared__ float qs[2][D];
     __shared__ float knew[D];
@@ -1720,9 +1728,9 @@ __global__ void talker_sample_kernel(TalkerSampleArgs a) {
     __shared__ int nwin;
     const int r = a.row0 + blockIdx.x;
     const int RT = a.R_total > 0 ? a.R_total : a.R;
-    const int np = a.n_past[r];
-    const int nt = a.n_text[r];
-    const bool was_done = a.done[r] != 0;
+    const int np = uniform_load(a.n_past + r);
+    const int nt = uniform_load(a.n_text + r);
+    const bool was_done = uniform_load(a.done + r) != 0;
     if (threadIdx.x == 0) nwin = np < 30 ? np : 30;
     if (threadIdx.x < 30 && threadIdx.x < np) {
         // last 30 emitted tokens (ring of 32)
@@ -1871,7 +1879,7 @@ __global__ void __launch_bounds__(256) cp_argmax_kernel(CpArgmaxArgs a) {
     float4 l0 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), l1 = l0;
     if (tid < n4) l0 = lg[tid];
     if (tid + 256 < n4) l1 = lg[tid + 256];
-    const int nf_r = a.n_frames[r];   // independent of the arg-max: requested with the logits, not after them
+    const int nf_r = uniform_load(a.n_frames + r);   // independent of the arg-max: a scalar load beside the logits' vector loads
     Q3_PH(0);
     {
         const float e[8] = {nan_as_inf(l0.x), nan_as_inf(l0.y), nan_as_inf(l0.z), nan_as_inf(l0.w),
