@@ -54,6 +54,11 @@ int voc_synthesize_max_samples(void* v, int n_tokens);
  * returns.  Process-wide; env Q3_VOC_EXACT=1 selects the exact path at load. */
 int voc_set_exact_fp32(int on);
 
+/* 1 (default): on the exact-f32 path a residual unit of the 96- / 192-channel decoder blocks (Snake, dilated 7-tap
+ * conv, Snake, 1x1 conv, + input) runs as ONE launch whose intermediate stays in MFMA accumulators; 0: one launch
+ * per conv (the 1x1 conv then sums its channels in a different order: results differ in the last f32 bit). */
+int voc_set_fused_units(int on);
+
 /* Cap the workgroups each vocoder kernel launch occupies (0 = one per output tile).  With a cap the
  * kernels walk their tiles persistently and leave the other compute units to a concurrently running
  * frame loop (talker / code predictor), which is latency-bound and would otherwise starve. */

@@ -74,30 +74,55 @@ __global__ void __launch_bounds__(256, MT >= 4 ? 3 : (MT == 3 ? 3 : 4)) conv_ker
             for (int i = 0; i < 16; i++) acc[mt][i] = 0.f;
         for (int ci0 = 0; ci0 < a.Cin; ci0 += KC) {
             __syncthreads();  // previous stage (or tile) fully consumed
-            // stage the weights of all taps for KC channels.  Packed layout [ci/8][k][ci%8][Mp] (rows contiguous):
-            // a tile row is TM contiguous floats, copied with 16-B loads / ds_write_b128, no transposition
-            for (int idx = tid; idx < KT * KC * (TM / 4); idx += 256) {
-                const int m4 = idx % (TM / 4), ci = (idx / (TM / 4)) % KC, k = idx / ((TM / 4) * KC);
-                const int m = m0 + m4 * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m < a.Mp) {
-                    const int cg = ci0 + ci;
-                    v = *(const float4*)(a.wk + ((((size_t)(cg >> 3) * KT + k) * 8 + (cg & 7)) * a.Mp + m));
-                }
-                *(float4*)(Ws + (k * KC + ci) * TMP + m4 * 4) = v;
+            // Staging issues EVERY global load of the stage before the first use (fixed trip counts, clamped addresses,
+            // predicated results): a load inside an `if` gets its own s_waitcnt in that branch, which made the stage a
+            // chain of dependent round trips (one per 256 elements) instead of one.
+            // Weights of all taps for KC channels.  Packed layout [ci/8][k][ci%8][Mp] (rows contiguous): a tile row is
+            // TM contiguous floats, copied with 16-B loads / ds_write_b128, no transposition
+            constexpr int WN = KT * KC * (TM / 4), WIT = (WN + 255) / 256;
+            float4 wv[WIT];
+#pragma unroll
+            for (int i = 0; i < WIT; i++) {
+                const int idx = tid + i * 256, ic = idx < WN ? idx : 0;
+                const int m4 = ic % (TM / 4), ci = (ic / (TM / 4)) % KC, k = ic / ((TM / 4) * KC);
+                const int m = m0 + m4 * 4, mc = m < a.Mp ? m : 0, cg = ci0 + ci;
+                wv[i] = *(const float4*)(a.wk + ((((size_t)(cg >> 3) * KT + k) * 8 + (cg & 7)) * a.Mp + mc));
+                if (m >= a.Mp) wv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            // the input line buffer (causal: columns left of 0 are zero; Snake(0) = 0 so padding commutes)
+            // the input line buffer (causal: columns left of 0 are zero; Snake(0) = 0 so padding commutes).  A thread
+            // stays on ONE channel of the stage (LPC lanes per channel), so its Snake parameters are two registers
+            constexpr int LPC = 256 / KC;
+            const int xci = tid / LPC, xl = tid - xci * LPC;
+            float al = 0.f, ib = 0.f;
+            if (a.alpha) { al = a.alpha[ci0 + xci]; ib = a.inv_beta[ci0 + xci]; }
+            auto store_w = [&]() {
+#pragma unroll
+                for (int i = 0; i < WIT; i++) {
+                    const int idx = tid + i * 256;
+                    if (idx < WN) {
+                        const int m4 = idx % (TM / 4), ci = (idx / (TM / 4)) % KC, k = idx / ((TM / 4) * KC);
+                        *(float4*)(Ws + (k * KC + ci) * TMP + m4 * 4) = wv[i];
+                    }
+                }
+            };
             if (KT == 1 && (a.Lin & 3) == 0) {
                 // one tap: no halo, the tile's 128 columns start 16-byte aligned -> 16-byte loads / ds_write_b128
-                for (int idx = tid; idx < KC * (VTN / 4); idx += 256) {
-                    const int ci = idx / (VTN / 4), c4 = (idx - ci * (VTN / 4)) * 4;
-                    const int gl = l0 + c4;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (gl < Lcols) {
-                        const int bb = a.flat_B > 0 ? gl / a.Lin : 0, l = gl - bb * a.Lin;   // (4 | Lin: a group stays in its chunk)
-                        v = *(const float4*)(xb + ((size_t)bb * a.Cin + ci0 + ci) * a.Lin + l);
+                constexpr int XJ = (VTN / 4 + LPC - 1) / LPC;
+                float4 xv[XJ];
+#pragma unroll
+                for (int j = 0; j < XJ; j++) {
+                    const int c4 = (xl + j * LPC) * 4, c4c = c4 < VTN ? c4 : 0;
+                    const int gl = l0 + c4c, glc = gl < Lcols ? gl : 0;
+                    const int bb = a.flat_B > 0 ? glc / a.Lin : 0, l = glc - bb * a.Lin;   // (4 | Lin: a group stays in its chunk)
+                    xv[j] = *(const float4*)(xb + ((size_t)bb * a.Cin + ci0 + xci) * a.Lin + l);
+                }
+                store_w();
+#pragma unroll
+                for (int j = 0; j < XJ; j++) {
+                    const int c4 = (xl + j * LPC) * 4;
+                    if (c4 < VTN) {
+                        float4 v = xv[j];
                         if (a.alpha) {
-                            const float al = a.alpha[ci0 + ci], ib = a.inv_beta[ci0 + ci];
                             float sn;
                             sn = __sinf(al * v.x); v.x = v.x + ib * (sn * sn);
                             sn = __sinf(al * v.y); v.y = v.y + ib * (sn * sn);
@@ -107,23 +132,39 @@ __global__ void __launch_bounds__(256, MT >= 4 ? 3 : (MT == 3 ? 3 : 4)) conv_ker
                         if (a.gelu) {
                             v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
                         }
+                        if (l0 + c4 >= Lcols) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        *(float4*)(Xs + xci * XW + c4) = v;
                     }
-                    *(float4*)(Xs + ci * XW + c4) = v;
                 }
-            } else
-            for (int idx = tid; idx < KC * XW; idx += 256) {
-                const int ci = idx / XW, col = idx - ci * XW;
-                const int l = l0 - halo + col;
-                float v = 0.f;
-                if (l >= 0 && l < a.Lin) {
-                    v = xb[(size_t)(ci0 + ci) * a.Lin + l];
-                    if (a.alpha) {
-                        const float sn = __sinf(a.alpha[ci0 + ci] * v);
-                        v = v + a.inv_beta[ci0 + ci] * (sn * sn);
+            } else {
+                constexpr int XJ = (VTN + (KT - 1) * 9 + LPC - 1) / LPC;   // dilation <= 9 (launcher)
+                constexpr int XB = XJ < 8 ? XJ : 8;                          // loads in flight per thread (register budget)
+#pragma unroll
+                for (int j0 = 0; j0 < XJ; j0 += XB) {
+                    float xv[XB];
+#pragma unroll
+                    for (int j = 0; j < XB; j++) {
+                        const int col = xl + (j0 + j) * LPC;
+                        const int l = l0 - halo + col, lc = (col < XW && l >= 0 && l < a.Lin) ? l : 0;
+                        xv[j] = xb[(size_t)(ci0 + xci) * a.Lin + lc];
                     }
-                    if (a.gelu) v = gelu_erf(v);
+                    if (j0 == 0) store_w();
+#pragma unroll
+                    for (int j = 0; j < XB; j++) {
+                        const int col = xl + (j0 + j) * LPC;
+                        if (col < XW) {
+                            const int l = l0 - halo + col;
+                            float v = xv[j];
+                            if (a.alpha) {
+                                const float sn = __sinf(al * v);
+                                v = v + ib * (sn * sn);
+                            }
+                            if (a.gelu) v = gelu_erf(v);
+                            if (l < 0 || l >= a.Lin) v = 0.f;
+                            Xs[xci * XW + col] = v;
+                        }
+                    }
                 }
-                Xs[idx] = v;
             }
             __syncthreads();
 #pragma unroll 1
@@ -232,6 +273,179 @@ static int launch_conv(hipStream_t s, const ConvArgs& a, int B) {
             Q3_LOG("voc conv: kernel with %d taps is not built (1, 2, 3, 7 are)", a.K);
             return -1;
     }
+}
+
+// ---------------------------------------------------------------------------
+// Fused residual unit of the decoder blocks at 96 / 192 channels (the two HBM-bound stages):
+//     y = x + conv1x1(Snake_b(conv7_dilated(Snake_a(x))))
+// in ONE launch.  The 7-tap conv's accumulators never leave the registers: the MFMA's D layout holds, per lane,
+// one column and 16 channels of each 32-row tile -- exactly a B operand of the 1x1 conv if its K axis is walked
+// in the order (tile, register): step t = (mt, q) contracts channel 32 mt + (q & 3) + 8 (q >> 2) in lanes 0-31
+// and that channel + 4 in lanes 32-63.  The 1x1 weights are stored at load time in that order as the matching A
+// operands (w1p[row tile][t][lane]), so the second GEMM is `mfma(Ws[t*64 + lane], acc1[mt][q], acc2)`.
+// HBM traffic per unit: x once (+ halo), y once -- against x, the copy kept for the residual (read + write), the
+// 7-tap output (write + read), the residual read and y for the three launches it replaces.
+struct ResUnitArgs {
+    const float* x = nullptr;     // [B][C][Lin]
+    float* y = nullptr;           // [B][C][Lin]
+    const float* w7 = nullptr;    // [C/8][7][8][C]   (conv_kernel's stage-major layout)
+    const float* w1p = nullptr;   // [C/32][C/2][64]  (A operands of the 1x1 conv in the order above)
+    const float *b7 = nullptr, *b1 = nullptr;                    // biases (may be null)
+    const float *al7 = nullptr, *ib7 = nullptr;                  // Snake of the unit's input
+    const float *al1 = nullptr, *ib1 = nullptr;                  // Snake between the convs
+    int Lin = 0, dil = 1, tiles_l = 0, n_tiles = 0;
+};
+
+static int g_voc_fuse = 1;   // 1 (default): residual units at <= 192 channels run fused on the exact path
+
+template <int MT>
+__global__ void __launch_bounds__(256, MT <= 3 ? 3 : 2) resunit_kernel(ResUnitArgs a) {
+    constexpr int C = 32 * MT, KT = 7, KC = 8, TMP = C + 4;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int halo = (KT - 1) * a.dil, XW = VTN + halo;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Ws = lds;                   // [KT][KC][TMP]; later one row tile of the 1x1 weights [C/2][64]
+    float* Xs = lds + KT * KC * TMP;   // [KC][XW]
+    float* Ps = Xs + KC * XW;          // [4][C]: b7, al1, ib1, b1
+    for (int i = tid; i < C; i += 256) {
+        Ps[i] = a.b7 ? a.b7[i] : 0.f;
+        Ps[C + i] = a.al1[i];
+        Ps[2 * C + i] = a.ib1[i];
+        Ps[3 * C + i] = a.b1 ? a.b1[i] : 0.f;
+    }
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int lx = tile % a.tiles_l, b = tile / a.tiles_l;
+        const int l0 = lx * VTN;
+        const float* xb = a.x + (size_t)b * C * a.Lin;
+        f16v acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[mt][i] = 0.f;
+        // ---- the dilated 7-tap conv (same staging and MFMA loop as conv_kernel<MT, 7, 8> over all C rows) ----
+        for (int ci0 = 0; ci0 < C; ci0 += KC) {
+            __syncthreads();
+            constexpr int WN = KT * KC * (C / 4), WIT = (WN + 255) / 256;
+            float4 wv[WIT];
+#pragma unroll
+            for (int i = 0; i < WIT; i++) {
+                const int idx = tid + i * 256, ic = idx < WN ? idx : 0;
+                const int m4 = ic % (C / 4), ci = (ic / (C / 4)) % KC, k = ic / ((C / 4) * KC);
+                const int cg = ci0 + ci;
+                wv[i] = *(const float4*)(a.w7 + (unsigned)((((cg >> 3) * KT + k) * 8 + (cg & 7)) * C + m4 * 4));
+            }
+            constexpr int LPC = 256 / KC, XJ = (VTN + (KT - 1) * 9 + LPC - 1) / LPC;
+            const int xci = tid / LPC, xl = tid - xci * LPC;
+            const float al = a.al7[ci0 + xci], ib = a.ib7[ci0 + xci];
+            float xv[XJ];
+#pragma unroll
+            for (int j = 0; j < XJ; j++) {
+                const int col = xl + j * LPC;
+                const int l = l0 - halo + col, lc = (col < XW && l >= 0 && l < a.Lin) ? l : 0;
+                xv[j] = xb[(unsigned)((ci0 + xci) * a.Lin + lc)];
+            }
+#pragma unroll
+            for (int i = 0; i < WIT; i++) {
+                const int idx = tid + i * 256;
+                if (idx < WN) {
+                    const int m4 = idx % (C / 4), ci = (idx / (C / 4)) % KC, k = idx / ((C / 4) * KC);
+                    *(float4*)(Ws + (k * KC + ci) * TMP + m4 * 4) = wv[i];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < XJ; j++) {
+                const int col = xl + j * LPC;
+                if (col < XW) {
+                    const int l = l0 - halo + col;
+                    const float sn = __sinf(al * xv[j]);
+                    float v = xv[j] + ib * (sn * sn);
+                    if (l < 0 || l >= a.Lin) v = 0.f;
+                    Xs[xci * XW + col] = v;
+                }
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int k = 0; k < KT; k++) {
+                const int off = halo - (KT - 1 - k) * a.dil + w * 32 + (lane & 31);
+#pragma unroll
+                for (int kk = 0; kk < KC; kk += 2) {
+                    const int ci = kk + (lane >> 5);
+                    const float bv = Xs[ci * XW + off];
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) {
+                        const float av = Ws[(k * KC + ci) * TMP + mt * 32 + (lane & 31)];
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // ---- bias + Snake on the accumulators: they become the 1x1 conv's B operands in place ----
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int c = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float v = acc[mt][r] + Ps[c];
+                const float sn = __sinf(Ps[C + c] * v);
+                acc[mt][r] = v + Ps[2 * C + c] * (sn * sn);
+            }
+        // ---- the 1x1 conv, one 32-row output tile at a time, + bias + residual ----
+        const int gl = l0 + w * 32 + (lane & 31);
+        const bool live = gl < a.Lin;
+#pragma unroll 1
+        for (int mt2 = 0; mt2 < MT; mt2++) {
+            float res[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = 32 * mt2 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                res[r] = xb[(unsigned)(m * a.Lin + (live ? gl : 0))];
+            }
+            __syncthreads();   // the 7-tap stage (or the previous row tile) is consumed by every wave
+#pragma unroll
+            for (int i = 0; i < MT; i++) {   // 32 C floats = 8 C float4 = MT per thread
+                const int idx = tid + i * 256;
+                *(float4*)(Ws + idx * 4) = *(const float4*)(a.w1p + (unsigned)(mt2 * 32 * C + idx * 4));
+            }
+            __syncthreads();
+            f16v o;
+#pragma unroll
+            for (int i = 0; i < 16; i++) o[i] = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int q = 0; q < 16; q++)
+                    o = __builtin_amdgcn_mfma_f32_32x32x2f32(Ws[(mt * 16 + q) * 64 + lane], acc[mt][q], o, 0, 0, 0);
+            if (live) {
+                float* yb = a.y + (size_t)b * C * a.Lin;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = 32 * mt2 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    __builtin_nontemporal_store(o[r] + Ps[3 * C + m] + res[r], &yb[(unsigned)(m * a.Lin + gl)]);
+                }
+            }
+        }
+    }
+}
+
+template <int MT>
+static int launch_resunit_t(hipStream_t s, ResUnitArgs a, int B) {
+    constexpr int C = 32 * MT;
+    const int halo = 6 * a.dil;
+    if (a.dil > 9) return -1;
+    const size_t lds = ((size_t)7 * 8 * (C + 4) + (size_t)8 * (VTN + halo) + 4 * C) * sizeof(float);
+    a.tiles_l = (a.Lin + VTN - 1) / VTN;
+    a.n_tiles = a.tiles_l * B;
+    int grid = a.n_tiles;
+    if (g_voc_max_wgs > 0 && grid > g_voc_max_wgs) grid = g_voc_max_wgs;
+    hipLaunchKernelGGL((resunit_kernel<MT>), dim3(grid), dim3(256), lds, s, a);
+    Q3_HIP(hipGetLastError(), -1);
+    return 0;
+}
+
+static bool resunit_channels(int c) { return c == 96 || c == 192; }
+
+static int launch_resunit(hipStream_t s, const ResUnitArgs& a, int C, int B) {
+    return C == 96 ? launch_resunit_t<3>(s, a, B) : C == 192 ? launch_resunit_t<6>(s, a, B) : -1;
 }
 
 // ---------------------------------------------------------------------------
@@ -756,6 +970,7 @@ struct VocOp {
     _Float16 *w_hi = nullptr, *w_lo = nullptr;  // split-precision weights (null: exact path only)
     int Mp128 = 0;
     float *p_sem = nullptr, *p_ac = nullptr;
+    float* w1p = nullptr;   // 1x1 conv closing a residual unit: A operands in resunit_kernel's K order
 };
 
 struct Voc {
@@ -982,6 +1197,24 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
                     if (!ok) break;
                 }
             }
+            if (op.op == VOP_CONV && op.k == 1 && op.cin == op.cout && resunit_channels(op.cin) &&
+                (op.flags & VF_RES_ADD) && (op.flags & VF_SNAKE)) {
+                // resunit_kernel's order: w1p[row tile][t = (mt, q)][lane = (h, m)] = W[32 tile + m][32 mt + (q&3) + 8 (q>>2) + 4 h]
+                const int Cc = op.cin;
+                std::vector<float> w1((size_t)Cc * Cc);
+                for (int t2 = 0; t2 < Cc / 32; t2++)
+                    for (int t = 0; t < Cc / 2; t++)
+                        for (int ln = 0; ln < 64; ln++) {
+                            const int mt = t / 16, q = t % 16, h = ln >> 5, m = ln & 31;
+                            const int c = 32 * mt + (q & 3) + 8 * (q >> 2) + 4 * h;
+                            w1[((size_t)t2 * (Cc / 2) + t) * 64 + ln] = wk[(size_t)(32 * t2 + m) * Cc + c];
+                        }
+                op.w1p = voc_up_host(v, w1);
+                if (!op.w1p) {
+                    ok = false;
+                    break;
+                }
+            }
             {   // [tap][row][cin] -> stage-major [cin/8][tap][cin%8][Mp]
                 const int KTAPS = op.op == VOP_CONV ? op.k : op.k / op.p0;
                 const int Mrows = op.op == VOP_CONV ? op.cout : op.cout * op.p0;
@@ -1116,6 +1349,11 @@ int voc_set_exact_fp32(int on) {
 
 int voc_set_narrow_k1(int on) {   // test hook: 128-column tiles for the 1-tap convs (default on)
     g_voc_narrow_k1 = on ? 1 : 0;
+    return 0;
+}
+
+int voc_set_fused_units(int on) {   // 1 (default): residual units at 96 / 192 channels run as one launch (exact path)
+    g_voc_fuse = on ? 1 : 0;
     return 0;
 }
 
@@ -1280,6 +1518,37 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
             cur = st.f32_idx;
             C = op.cout;
             if (op.op == VOP_CONVT) L *= op.p0;
+        } else if (g_voc_fuse && op.op == VOP_CONV && op.k == 7 && (op.flags & VF_RES_SAVE) && (op.flags & VF_SNAKE) &&
+                   op.cin == op.cout && resunit_channels(op.cin) && i + 1 < nrun && v->ops[i + 1].w1p && st.f32_cur) {
+            // a whole residual unit (this 7-tap conv + the 1x1 conv that closes it) in one launch
+            const VocOp& op1 = v->ops[i + 1];
+            cur = st.f32_idx;
+            ResUnitArgs ra;
+            ra.x = v->buf[cur];
+            ra.y = v->buf[cur ^ 1];
+            ra.w7 = op.w;
+            ra.w1p = op1.w1p;
+            ra.b7 = op.bias;
+            ra.b1 = op1.bias;
+            ra.al7 = op.alpha;
+            ra.ib7 = op.inv_beta;
+            ra.al1 = op1.alpha;
+            ra.ib1 = op1.inv_beta;
+            ra.Lin = (int)L;
+            ra.dil = op.p0;
+            if (launch_resunit(v->s, ra, op.cin, B)) return -1;
+            cur ^= 1;
+            st.f32_idx = cur;
+            st.f32_cur = true;
+            st.planes = -1;
+            if (op_ms) {
+                hipEventRecord(v->e1, v->s);
+                hipStreamSynchronize(v->s);
+                hipEventElapsedTime(&op_ms[i], v->e0, v->e1);
+                op_ms[i + 1] = 0.f;
+            }
+            i++;   // the 1x1 conv is done
+            continue;
         } else {
             if (!st.f32_cur) return -1;
             cur = st.f32_idx;

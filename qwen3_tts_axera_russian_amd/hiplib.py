@@ -83,6 +83,7 @@ def load(path: str | None = None):
     _sig(lib, "voc_synthesize_max_samples", c_int, [c_void_p, c_int])
     _sig(lib, "voc_set_max_workgroups", c_int, [c_int])
     _sig(lib, "voc_set_exact_fp32", c_int, [c_int])
+    _sig(lib, "voc_set_fused_units", c_int, [c_int])
     _sig(lib, "voc_last_decode_ms", c_float, [c_void_p])
     _sig(lib, "voc_decode_flops", ctypes.c_double, [c_void_p, c_int])
     # include/qwen3tts_text.h

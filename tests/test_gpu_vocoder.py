@@ -176,6 +176,31 @@ def test_full_size_table_matches_torch_reference_in_both_arithmetic_modes(gpu_li
     gpu_lib.voc_set_exact_fp32(0)
 
 
+def test_fused_residual_units_equal_the_per_conv_launches(gpu_lib):
+    """The 96- / 192-channel residual units run as one launch on the exact path (voc_set_fused_units, default on):
+    the dilated 7-tap conv's accumulators feed the 1x1 conv as MFMA operands in registers.  Same arithmetic except
+    the order in which the 1x1 conv sums its channels: outputs of the whole default table agree to 2e-6 of full
+    scale with the three-launch form, at a ragged batch (3 chunks) so the column tail of the tiling is covered."""
+    path = os.path.join(CACHE, "voc_whole_s1234.q3w")
+    if not os.path.exists(path):
+        W.write_pack(path, {"voc_chunk": 64.0}, W.make_synthetic_voc(W.VocConfig(), seed=1234))
+    codes = np.random.default_rng(33).integers(0, 2048, size=(3, 64, 16)).astype(np.int64)
+    gpu_lib.voc_set_exact_fp32(1)
+    outs = []
+    for fused in (1, 0):
+        gpu_lib.voc_set_fused_units(fused)
+        v = Voc(gpu_lib, path, max_batch=3)
+        outs.append(v.decode(codes).copy())
+        ms = gpu_lib.voc_last_decode_ms(v.h)
+        v.close()
+        print(f"fused={fused}: {ms:.2f} ms for 3 chunks")
+    gpu_lib.voc_set_fused_units(1)
+    gpu_lib.voc_set_exact_fp32(0)
+    err = float(np.abs(outs[0] - outs[1]).max())
+    print(f"fused vs per-conv launches: max abs diff {err:.2e}")
+    assert np.abs(outs[1]).max() > 0.01 and err < 2e-6
+
+
 def test_decode_from_a_converted_speech_tokenizer_directory(gpu_lib, tmp_path):
     """A speech_tokenizer/ directory (VOC_NAMES layout, layer scales as separate tensors) converted by
     weights.convert_speech_tokenizer decodes to the waveform of the table it was exported from (2e-6: the layer
