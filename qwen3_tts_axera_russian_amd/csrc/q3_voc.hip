@@ -17,6 +17,7 @@
 #include "q3_common.h"
 
 #include <cmath>
+#include <utility>
 
 namespace q3 {
 
@@ -52,7 +53,7 @@ constexpr int VTN = 128;   // output columns per workgroup (4 waves x 32)
 // conv_kernel<MT, KT, KC>: MT 32-row MFMA tiles per wave, KT taps, KC input channels per LDS stage.
 // Staging goes global -> LDS directly; ~4 workgroups per CU hide its latency (a register-staged software
 // pipeline was tried: 199-256 VGPRs, one workgroup per SIMD, 1.6x slower at 32 chunks).
-template <int MT, int KT, int KC>
+template <int MT, int KT, int KC, bool CT = false>   // CT: transposed conv (stride > 1, no residual), stores go through an LDS slab
 __global__ void __launch_bounds__(256, MT >= 4 ? 3 : (MT == 3 ? 3 : 4)) conv_kernel(ConvArgs a) {
     constexpr int TM = 32 * MT, TMP = TM + 4, Q = KC / 4;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -86,7 +87,7 @@ __global__ void __launch_bounds__(256, MT >= 4 ? 3 : (MT == 3 ? 3 : 4)) conv_ker
                 const int idx = tid + i * 256, ic = idx < WN ? idx : 0;
                 const int m4 = ic % (TM / 4), ci = (ic / (TM / 4)) % KC, k = ic / ((TM / 4) * KC);
                 const int m = m0 + m4 * 4, mc = m < a.Mp ? m : 0, cg = ci0 + ci;
-                wv[i] = *(const float4*)(a.wk + ((((size_t)(cg >> 3) * KT + k) * 8 + (cg & 7)) * a.Mp + mc));
+                wv[i] = *(const float4*)(a.wk + (unsigned)((((cg >> 3) * KT + k) * 8 + (cg & 7)) * a.Mp + mc));
                 if (m >= a.Mp) wv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             // the input line buffer (causal: columns left of 0 are zero; Snake(0) = 0 so padding commutes).  A thread
@@ -114,7 +115,7 @@ __global__ void __launch_bounds__(256, MT >= 4 ? 3 : (MT == 3 ? 3 : 4)) conv_ker
                     const int c4 = (xl + j * LPC) * 4, c4c = c4 < VTN ? c4 : 0;
                     const int gl = l0 + c4c, glc = gl < Lcols ? gl : 0;
                     const int bb = a.flat_B > 0 ? glc / a.Lin : 0, l = glc - bb * a.Lin;   // (4 | Lin: a group stays in its chunk)
-                    xv[j] = *(const float4*)(xb + ((size_t)bb * a.Cin + ci0 + xci) * a.Lin + l);
+                    xv[j] = *(const float4*)(xb + (unsigned)((bb * a.Cin + ci0 + xci) * a.Lin + l));
                 }
                 store_w();
 #pragma unroll
@@ -146,7 +147,7 @@ __global__ void __launch_bounds__(256, MT >= 4 ? 3 : (MT == 3 ? 3 : 4)) conv_ker
                     for (int j = 0; j < XB; j++) {
                         const int col = xl + (j0 + j) * LPC;
                         const int l = l0 - halo + col, lc = (col < XW && l >= 0 && l < a.Lin) ? l : 0;
-                        xv[j] = xb[(size_t)(ci0 + xci) * a.Lin + lc];
+                        xv[j] = xb[(unsigned)((ci0 + xci) * a.Lin + lc)];
                     }
                     if (j0 == 0) store_w();
 #pragma unroll
@@ -187,7 +188,39 @@ __global__ void __launch_bounds__(256, MT >= 4 ? 3 : (MT == 3 ? 3 : 4)) conv_ker
         const int be = a.flat_B > 0 ? gl / a.Lin : b;
         const int l = a.flat_B > 0 ? gl - be * a.Lin : gl;
         const int Lout = a.Lin * a.stride;
-        if (gl < Lcols) {
+        if constexpr (CT) {
+            // transposed conv: row m = co * stride + p lands at y[co][l * stride + p] -- stored straight from the D
+            // layout that is one 4-byte store per lane at a stride of `stride` floats (32-byte sectors filled a few
+            // bytes at a time).  Each 32-row tile goes through LDS instead and leaves as runs of 128 * stride
+            // consecutive floats per output channel.
+            constexpr int TP = VTN + 1;
+            float* T = lds;   // [32][TP] (the launcher sizes the LDS request for it)
+            const int s = a.stride;
+#pragma unroll   // (static register indices: a rolled loop would put the accumulators in scratch)
+            for (int mt = 0; mt < MT; mt++) {
+                __syncthreads();   // the last stage's operands (or the previous slab) are consumed
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    T[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * TP + w * 32 + (lane & 31)] = acc[mt][r];
+                __syncthreads();
+                const int m_lo = m0 + mt * 32, m_hi = (m_lo + 32 < a.M) ? m_lo + 32 : a.M;
+                if (m_lo < m_hi) {
+                    const int ncol = (a.Lin - l0 < VTN) ? a.Lin - l0 : VTN;   // live columns of this tile
+                    for (int co = m_lo / s; co * s < m_hi; co++) {
+                        const float bv = a.bias ? a.bias[co] : 0.f;
+                        float* yrow = a.y + (size_t)b * a.Cout * Lout + (unsigned)(co * Lout + l0 * s);
+                        for (int j = tid; j < ncol * s; j += 256) {
+                            const int lc = j / s, ph = j - lc * s, m = co * s + ph;
+                            if (m >= m_lo && m < m_hi) {
+                                float v = T[(m - m_lo) * TP + lc] + bv;
+                                if (a.clamp) v = fminf(fmaxf(v, -1.f), 1.f);
+                                __builtin_nontemporal_store(v, &yrow[j]);
+                            }
+                        }
+                    }
+                }
+            }
+        } else if (gl < Lcols) {
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -196,7 +229,7 @@ __global__ void __launch_bounds__(256, MT >= 4 ? 3 : (MT == 3 ? 3 : 4)) conv_ker
                     if (m < a.M) {
                         const int co = a.stride == 1 ? m : m / a.stride;
                         const int p = a.stride == 1 ? 0 : m % a.stride;
-                        const size_t idx = ((size_t)be * a.Cout + co) * Lout + (size_t)l * a.stride + p;
+                        const unsigned idx = (unsigned)((be * a.Cout + co) * Lout + l * a.stride + p);   // (launcher: < 2^31)
                         float v = acc[mt][r];
                         if (a.bias) v += a.bias[co];
                         if (a.res) v += a.res[idx];
@@ -211,8 +244,11 @@ __global__ void __launch_bounds__(256, MT >= 4 ? 3 : (MT == 3 ? 3 : 4)) conv_ker
     }  // tile loop
 }
 
-template <int MT, int KT, int KC>
+template <int MT, int KT, int KC, bool CT = false>
 static int launch_conv_t(hipStream_t s, const ConvArgs& a, int B) {
+    if constexpr (!CT && KT <= 2) {
+        if (a.stride > 1 && a.res == nullptr) return launch_conv_t<MT, KT, KC, true>(s, a, B);
+    }
     constexpr int TM = 32 * MT, TMP = TM + 4;
     const int halo = (KT - 1) * a.dil;
     if (a.dil > 9) {
@@ -220,6 +256,7 @@ static int launch_conv_t(hipStream_t s, const ConvArgs& a, int B) {
         return -1;
     }
     size_t lds = ((size_t)KT * KC * TMP + (size_t)KC * (VTN + halo)) * sizeof(float);
+    if (CT && lds < (size_t)32 * (VTN + 1) * sizeof(float)) lds = (size_t)32 * (VTN + 1) * sizeof(float);   // store slab
     // experiment knob: Q3_VOC_LDS_PAD=bytes raises every conv launch's LDS request, i.e. lowers the vocoder's
     // residency per CU evenly (room for the frame loop's workgroups when the two run side by side)
     static const size_t lds_pad = getenv("Q3_VOC_LDS_PAD") ? (size_t)atol(getenv("Q3_VOC_LDS_PAD")) : 0;
@@ -227,19 +264,26 @@ static int launch_conv_t(hipStream_t s, const ConvArgs& a, int B) {
         lds = lds_pad;
         static bool attr = false;
         if (!attr) {
-            Q3_HIP(hipFuncSetAttribute((const void*)conv_kernel<MT, KT, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), -1);
+            Q3_HIP(hipFuncSetAttribute((const void*)conv_kernel<MT, KT, KC, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), -1);
             attr = true;
         }
     }
     ConvArgs c = a;
     c.Mp = (a.M + 3) / 4 * 4;
     c.flat_B = (KT == 1 && a.stride == 1 && (a.Lin & 3) == 0) ? B : 0;
+    {   // the kernel indexes activations with 32-bit offsets from a.x / a.y (all chunks: the epilogue's `be` is per lane)
+        const size_t cmax = (size_t)(a.Cin > a.Cout ? a.Cin : a.Cout);
+        if ((size_t)B * cmax * a.Lin * a.stride >= ((size_t)1 << 31)) {
+            Q3_LOG("voc conv: activation of %d x %zu x %d floats is beyond the kernel's 32-bit indexing", B, cmax, a.Lin * a.stride);
+            return -1;
+        }
+    }
     c.tiles_l = ((c.flat_B > 0 ? a.Lin * B : a.Lin) + VTN - 1) / VTN;
     c.tiles_m = (a.M + TM - 1) / TM;
     c.n_tiles = c.tiles_l * c.tiles_m * (c.flat_B > 0 ? 1 : B);
     int grid = c.n_tiles;
     if (g_voc_max_wgs > 0 && grid > g_voc_max_wgs) grid = g_voc_max_wgs;
-    hipLaunchKernelGGL((conv_kernel<MT, KT, KC>), dim3(grid), dim3(256), lds, s, c);
+    hipLaunchKernelGGL((conv_kernel<MT, KT, KC, CT>), dim3(grid), dim3(256), lds, s, c);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
 }
@@ -1474,9 +1518,10 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
             in = v->buf[cur];
             out = v->buf[cur ^ 1];
             if (op.flags & VF_RES_SAVE) {
-                Q3_HIP(hipMemcpyAsync(v->buf[2], in, sizeof(float) * (size_t)B * C * L, hipMemcpyDeviceToDevice, v->s), -1);
-                res = v->buf[2];
-                st.res = res;
+                // the unit's input is needed again two ops later: it becomes buf[2] (a pointer swap, no copy), where
+                // the ping-pong of the ops in between does not write
+                std::swap(v->buf[2], v->buf[cur]);
+                in = res = st.res = v->buf[2];
             }
             const unsigned lb = (unsigned)((L + 255) / 256);
             if (op.op == VOP_DWCONV)
@@ -1578,10 +1623,10 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
                 a.M = op.cout * op.p0;
             }
             if (op.flags & VF_RES_SAVE) {
-                // the unit's input is needed again after two convs: keep it where the ping-pong will not write
-                Q3_HIP(hipMemcpyAsync(v->buf[2], in, sizeof(float) * (size_t)B * C * L, hipMemcpyDeviceToDevice, v->s), -1);
-                res = v->buf[2];
-                st.res = res;
+                // the unit's input is needed again after two convs: it becomes buf[2] (pointer swap), out of the ping-pong
+                std::swap(v->buf[2], v->buf[cur]);
+                res = st.res = v->buf[2];
+                a.x = res;
             }
             if (op.flags & VF_RES_ADD) a.res = res ? res : st.res;
             if (launch_conv(v->s, a, B)) return -1;
