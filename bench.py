@@ -29,6 +29,10 @@ import os
 import sys
 import time
 
+# One hardware queue for all of the process's streams: the library sets this when it is loaded (csrc/q3_common.cpp has
+# the measurements); a rank started under torch.distributed initialises the HIP runtime before that, so say it here too.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
