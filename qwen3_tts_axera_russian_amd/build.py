@@ -36,6 +36,59 @@ def _newer(dst: str, srcs) -> bool:
     return all(os.path.getmtime(s) <= t for s in srcs)
 
 
+# kernels that must not spill registers to scratch: the fused residual units are HBM-bound stages, scratch traffic is
+# HBM traffic (round 1 shipped a 96-channel conv variant with 12 spilled registers = +0.19 GB per launch)
+NO_SPILL = ("resunit_kernel", "linear_kernelILi1ELi1E", "linear_kernelILi1ELi2E", "linear_kernelILi2ELi1E",
+            "linear_kernelILi2ELi2E", "attn_kernel", "attn_short_kernel", "cp_argmax_kernel", "talker_sample_kernel")
+
+
+def kernel_resources(lib_path: str):
+    """-> {kernel symbol: (vgprs, agprs, spilled vgprs, scratch bytes)} of the gfx950 code objects inside a built
+    shared library (the metadata notes of the fat binary's AMDGPU ELF images)."""
+    import re
+    import struct
+    import tempfile
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    d = open(lib_path, "rb").read()
+    res = {}
+    i = d.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    while i >= 0:
+        n = struct.unpack_from("<Q", d, i + 24)[0]
+        off = i + 32
+        for _ in range(n):
+            o, sz, ts = struct.unpack_from("<QQQ", d, off)
+            off += 24
+            triple = d[off:off + ts].decode()
+            off += ts
+            if ARCH in triple and sz:
+                with tempfile.NamedTemporaryFile(suffix=".elf") as f:
+                    f.write(d[i + o:i + o + sz])
+                    f.flush()
+                    notes = subprocess.run([readelf, "--notes", f.name], capture_output=True, text=True).stdout
+                for blk in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:
+                    def g(key, blk=blk):
+                        m = re.search(r"\." + key + r":\s+(\S+)", blk)
+                        return m.group(1) if m else "0"
+                    res[g("name")] = (int(g("vgpr_count")), int(blk.split()[0]), int(g("vgpr_spill_count")),
+                                      int(g("private_segment_fixed_size")))
+        i = d.find(b"__CLANG_OFFLOAD_BUNDLE__", i + 1)
+    return res
+
+
+def check_spills(lib_path: str, verbose: bool = False) -> None:
+    """Fail the build when a kernel of NO_SPILL spills registers; list the others that do."""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        return
+    bad, others = [], []
+    for name, (v, a, spill, scratch) in sorted(kernel_resources(lib_path).items()):
+        if spill:
+            (bad if any(k in name for k in NO_SPILL) else others).append(f"{name}: {spill} spilled VGPRs ({scratch} B scratch)")
+    if verbose and others:
+        print("kernels with spilled registers (not on the no-spill list):\n  " + "\n  ".join(others), flush=True)
+    if bad:
+        raise RuntimeError("register spills in kernels that must not spill:\n  " + "\n  ".join(bad))
+
+
 def build(force: bool = False, verbose: bool = False, timeline: bool = False) -> str:
     """timeline=True builds lib/libqwen3tts_tl.so with in-kernel time stamps (diagnostics only)."""
     os.makedirs(LIB, exist_ok=True)
@@ -87,6 +140,7 @@ def build(force: bool = False, verbose: bool = False, timeline: bool = False) ->
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
+        check_spills(out, verbose)
         alias = os.path.join(LIB, "llama_wrapper.so")
         if not os.path.exists(alias) or os.path.getmtime(alias) < os.path.getmtime(out):
             shutil.copyfile(out, alias)

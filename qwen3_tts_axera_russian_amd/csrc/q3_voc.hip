@@ -293,6 +293,16 @@ static int launch_conv_mt(hipStream_t s, const ConvArgs& a, int B) {
     const int t32 = (a.M + 31) / 32;  // 32-row MFMA tiles needed
     int mt = 4;
     if (t32 % 4 != 0) mt = (t32 % 3 == 0) ? 3 : (t32 % 2 == 0) ? 2 : (t32 < 4 ? t32 : 4);
+    // short activations (the 12.5 Hz / 25 Hz stages: 64-256 columns per chunk): tall tiles leave most CUs without a
+    // workgroup (1024 -> 512 over 2048 columns is 4 x 16 = 64 tiles of 128 rows) -- take shorter tiles until the grid
+    // covers the chip
+    // covers the chip twice (measured, 32 chunks: pre-transformer 5.8 -> 4.2 ms, the 4096 -> 1024 ConvNeXt conv 0.83 -> 0.62)
+    static const int fill = getenv("Q3_VOC_FILL") ? atoi(getenv("Q3_VOC_FILL")) : 512;
+    if (fill > 0) {
+        const long cols = (KT == 1 && a.stride == 1 && (a.Lin & 3) == 0) ? (long)a.Lin * B : (long)a.Lin;
+        const long col_tiles = (cols + VTN - 1) / VTN * ((KT == 1 && a.stride == 1 && (a.Lin & 3) == 0) ? 1 : B);
+        while (mt > 1 && col_tiles * ((t32 + mt - 1) / mt) < fill) mt = (mt == 4 || mt == 2) ? mt / 2 : 1;
+    }
     switch (mt) {
         case 1: return launch_conv_t<1, KT, KC>(s, a, B);
         case 2: return launch_conv_t<2, KT, KC>(s, a, B);
@@ -308,6 +318,12 @@ static int launch_conv(hipStream_t s, const ConvArgs& a, int B) {
         return -1;
     }
     // few taps: deeper channel stages keep enough MFMAs between barriers
+    // one / two taps: 32-channel stages where the activation is short (few tiles: fewer barriers per tile), 16-channel
+    // stages on the long ones (the 32-channel variants of the 128-row tile spill 27-35 registers; measured at 32 chunks:
+    // 384 -> 384 k1 1.74 -> 1.44 ms, 768 -> 768 k1 1.06 -> 0.94)
+    static const int kc_max = getenv("Q3_VOC_KC_MAX") ? atoi(getenv("Q3_VOC_KC_MAX")) : 0;
+    const bool long_act = (long)a.Lin * B >= 32768;
+    if ((kc_max ? kc_max < 32 : long_act) && c % 16 == 0 && (a.K == 1 || a.K == 2)) return a.K == 1 ? launch_conv_mt<1, 16>(s, a, B) : launch_conv_mt<2, 16>(s, a, B);
     switch (a.K) {
         case 1: return c % 32 == 0 ? launch_conv_mt<1, 32>(s, a, B) : c % 16 == 0 ? launch_conv_mt<1, 16>(s, a, B) : launch_conv_mt<1, 8>(s, a, B);
         case 2: return c % 32 == 0 ? launch_conv_mt<2, 32>(s, a, B) : c % 16 == 0 ? launch_conv_mt<2, 16>(s, a, B) : launch_conv_mt<2, 8>(s, a, B);
@@ -438,11 +454,15 @@ __global__ void __launch_bounds__(256, MT <= 3 ? 3 : 2) resunit_kernel(ResUnitAr
         const bool live = gl < a.Lin;
 #pragma unroll 1
         for (int mt2 = 0; mt2 < MT; mt2++) {
+            // element (row m, column gl): the row splits into a wave-uniform part (32 mt2 + the register's row: scalar
+            // address arithmetic) and ONE per-lane offset; written as 16 per-lane offsets the compiler computed all of
+            // them (and the 16 of the stores) at kernel entry and spilled them (36 registers, round 2)
+            const unsigned lane_off = (unsigned)(4 * (lane >> 5) * a.Lin + (live ? gl : 0));
             float res[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int m = 32 * mt2 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                res[r] = xb[(unsigned)(m * a.Lin + (live ? gl : 0))];
+                const float* rowp = xb + (unsigned)((32 * mt2 + (r & 3) + 8 * (r >> 2)) * a.Lin);
+                res[r] = rowp[lane_off];
             }
             __syncthreads();   // the 7-tap stage (or the previous row tile) is consumed by every wave
 #pragma unroll
@@ -463,8 +483,9 @@ __global__ void __launch_bounds__(256, MT <= 3 ? 3 : 2) resunit_kernel(ResUnitAr
                 float* yb = a.y + (size_t)b * C * a.Lin;
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    const int m = 32 * mt2 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    __builtin_nontemporal_store(o[r] + Ps[3 * C + m] + res[r], &yb[(unsigned)(m * a.Lin + gl)]);
+                    const int mu = 32 * mt2 + (r & 3) + 8 * (r >> 2);
+                    float* rowp = yb + (unsigned)(mu * a.Lin);
+                    __builtin_nontemporal_store(o[r] + Ps[3 * C + mu + 4 * (lane >> 5)] + res[r], &rowp[lane_off]);
                 }
             }
         }
