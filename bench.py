@@ -10,8 +10,9 @@ anything touches a GPU) and relays rank 0's JSON line.
 One "step" = one pass of the hot path over one batch of synthetic utterances: ragged prefill of B
 prompts + F autoregressive frames (talker step, 15-group code predictor, feedback) for all of them
 + the fp32 vocoder chunk (F=64 frames -> 5.12 s of 24 kHz audio) of every utterance; the vocoder of
-step i runs on its own stream while the frame loop of step i+1 proceeds (the streaming overlap of the
-reference client, tts_client.py:188-197).  Weights and prefix embeddings are resident before the
+step i is submitted from a second thread on its own stream while the frame loop of step i+1 proceeds (the
+streaming arrangement of the reference client, tts_client.py:188-197; on the chip the two do not overlap --
+profiles/r02_coscheduling.md -- so a step costs their sum).  Weights and prefix embeddings are resident before the
 timed region.  Utterances are independent:
 the N*B utterances of a job (config 4: 256 = the 32 prompts x 8) are sorted by expected length (3 frames per
 text token, the reference's own estimate: llamacpp_talker_server.py:174) and dealt round-robin to the N ranks; no
@@ -60,6 +61,9 @@ def parse():
     ap.add_argument("--no-vocoder", action="store_true", help="time the talker + code-predictor loop only")
     ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 latency leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-timeline", action="store_true",
+                    help="skip the in-graph timeline child process (use under rocprofv3: the profiler follows the child, "
+                         "whose graph replay it cannot trace); the roofline then comes from the stand-alone launch loop")
     ap.add_argument("--cpu-frames", type=int, default=96, help="frames of the CPU baseline sample (~12 s at 8 frames/s)")
     ap.add_argument("--backend", default=os.environ.get("Q3_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="process-group backend (nccl = RCCL; gloo only for the CPU test of the rank logic)")
@@ -221,7 +225,7 @@ def kv_bytes_per_step(n_text, frames, cfg):
 PMC_TRAFFIC_GATEUP = {32: 13.22e6 + 0.197e6, 1: 12.89e6 + 0.012e6}
 
 
-def dominant_kernel_roofline(rows, cache):
+def dominant_kernel_roofline(rows, cache, timeline=True):
     """The dominant kernel of the path by bytes: the fused (RMSNorm-folded) gate/up GEMM -> SwiGLU launch (12.58 MB of
     fp16 weights, 36 % of a layer's stream).  Its launch duration is measured IN the replayed frame graph -- the chain
     the benchmark times, real activations -- by scripts/frame_timeline.py (child process, timeline build of the
@@ -235,7 +239,7 @@ def dominant_kernel_roofline(rows, cache):
     algo = N * K * 2 + rows * K * 2 + rows * (N // 2) * 2      # weights + fp16 activations in + fp16 out
     tl_lib = os.path.join(ROOT, "qwen3_tts_axera_russian_amd", "lib", "libqwen3tts_tl.so")
     us, how, table = None, None, None
-    if os.path.exists(tl_lib):
+    if timeline and os.path.exists(tl_lib):
         try:
             r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "frame_timeline.py"), "--json", "--batch",
                                 str(int(rows)), "--cache", cache], capture_output=True, text=True, timeout=600)
@@ -492,7 +496,7 @@ def main():
                                            None if a.no_vocoder else make_voc_pack(a.cache, a.seed, rank, barrier))
     if rank == 0:
         # the dominant kernel's in-graph launch duration (child process; this process's engines are gone by now)
-        out["roofline"], table = dominant_kernel_roofline(B, a.cache)
+        out["roofline"], table = dominant_kernel_roofline(B, a.cache, timeline=not a.no_timeline)
         if table is not None:
             out["frame_timeline"] = {k: {"n": v["n"], "span_us": v["mean_span_us"], "gap_us": v["mean_gap_before_us"]}
                                      for k, v in table["kinds"].items()}

@@ -1,13 +1,15 @@
-// Synthetic neighbour kernels for scripts/coschedule_probe.py (diagnostics; not part of the product library).
-// nb_kernel<NA>: per iteration `nld` 16-byte global loads (+ stores), `nlds` LDS write/read pairs, `nmfma` x NA dependent
-// fp32 MFMAs (32x32x2, 64 cycles each) -- the MFMA duty cycle, the grid (all resident or refilling), the LDS request and
-// the register count (NA accumulator tiles) of a neighbour are the knobs.  Build: hipcc --offload-arch=gfx950 -O3 -shared
-// -fPIC nb.hip -o libnb.so
+// Synthetic neighbour kernels for scripts/coschedule_probe.py and scripts/coschedule/*.py (diagnostics; not part of
+// the product library).  nb_kernel<NA>: per iteration `nld` 16-byte global loads (+ stores), `nlds` LDS write/read pairs,
+// `nmfma` x NA dependent fp32 MFMAs (32x32x2, 64 cycles each) -- the MFMA duty cycle, the grid (all resident or
+// refilling), the LDS request and the register count (NA accumulator tiles) of a neighbour are the knobs; nb_set_gap puts
+// a pause (s_nop / s_sleep / one VALU op / one LDS read) after every n-th MFMA.
+// Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC nb.hip -o libnb.so
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 typedef float f16v __attribute__((ext_vector_type(16)));
 
+__device__ int g_gap_every = 0, g_gap_kind = 0;
 template <int NA>
 __global__ void __launch_bounds__(256) nb_kernel(int iters, int nmfma, int nlds, int nld, const float4* __restrict__ buf,
                                                  unsigned nbuf4, int do_store, float4* __restrict__ wbuf, float* sink) {
@@ -33,9 +35,20 @@ __global__ void __launch_bounds__(256) nb_kernel(int iters, int nmfma, int nlds,
             lds[(threadIdx.x + l * 257) & 4095] = av;
             av += lds[(threadIdx.x * 3 + l) & 4095];
         }
+        const int ge = g_gap_every, gk = g_gap_kind;
+        int since = 0;
         for (int m = 0; m < nmfma; m++) {
 #pragma unroll
             for (int a = 0; a < NA; a++) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a], 0, 0, 0);
+            if (ge > 0 && ++since >= ge) {
+                since = 0;
+                if (gk == 1) { asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory"); }
+                else if (gk == 2) { __builtin_amdgcn_s_sleep(1); }
+                else if (gk == 3) { __builtin_amdgcn_s_sleep(4); }
+                else if (gk == 4) { asm volatile("v_mov_b32 %0, %0" : "+v"(av)); }
+                else if (gk == 5) { av += lds[threadIdx.x]; }
+                else if (gk == 6) { asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory"); }
+            }
         }
     }
     float s = g.x + g.y + g.z + g.w + av;
@@ -118,4 +131,10 @@ extern "C" float nb_wait(int poll_us) {
     float ms = 0;
     hipEventElapsedTime(&ms, g_e0, g_e1);
     return ms;
+}
+
+extern "C" int nb_set_gap(int every, int kind) {
+    hipMemcpyToSymbol(HIP_SYMBOL(g_gap_every), &every, sizeof(int));
+    hipMemcpyToSymbol(HIP_SYMBOL(g_gap_kind), &kind, sizeof(int));
+    return 0;
 }
