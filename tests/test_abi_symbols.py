@@ -69,3 +69,41 @@ def test_fails_loudly_without_gpu_or_weights(lib, tmp_path):
     from qwen3_tts_axera_russian_amd.llama_cpp_bindings import LlamaCppModel
     with pytest.raises(RuntimeError):
         LlamaCppModel(str(tmp_path / "nope.q3w"))
+
+
+def _queues_seen_by_a_fresh_process(preset):
+    """GPU_MAX_HW_QUEUES in the C environment of a fresh process after the library was loaded."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("GPU_MAX_HW_QUEUES", None)
+    if preset is not None:
+        env["GPU_MAX_HW_QUEUES"] = preset
+    code = ("import ctypes\n"
+            "from qwen3_tts_axera_russian_amd import build\n"
+            "ctypes.CDLL(build.build())\n"
+            "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p\n"
+            "print(libc.getenv(b'GPU_MAX_HW_QUEUES').decode())\n")
+    return subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, env=env, text=True).strip().splitlines()[-1]
+
+
+def test_library_asks_for_one_hardware_queue_unless_the_user_chose():
+    """csrc/q3_common.cpp: a constructor sets GPU_MAX_HW_QUEUES=1 before the HIP runtime reads its flags (DESIGN.md 4,
+    'one hardware queue'); a value the user exported wins."""
+    assert _queues_seen_by_a_fresh_process(None) == "1"
+    assert _queues_seen_by_a_fresh_process("4") == "4"
+
+
+def test_hot_kernels_do_not_spill_registers():
+    """build.check_spills: the fused residual units (HBM-bound: scratch traffic is HBM traffic) and the frame loop's
+    kernels keep everything in registers; read from the metadata notes of the built gfx950 code objects."""
+    from qwen3_tts_axera_russian_amd import LIB_PATH, build
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("llvm-readelf not installed")
+    res = build.kernel_resources(LIB_PATH)
+    fused = {k: v for k, v in res.items() if "resunit_kernel" in k}
+    assert len(fused) == 2, sorted(fused)
+    for name, (vgprs, agprs, spilled, scratch) in fused.items():
+        assert spilled == 0 and scratch == 0, (name, vgprs, spilled, scratch)
+    build.check_spills(LIB_PATH)   # raises on a spill in any kernel of build.NO_SPILL
+    assert any("linear_kernel" in k for k in res) and any("conv_kernel" in k for k in res)
