@@ -73,15 +73,19 @@ __global__ void __launch_bounds__(256, MT >= 4 ? 3 : (MT == 3 ? 3 : 4)) conv_ker
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[mt][i] = 0.f;
-        for (int ci0 = 0; ci0 < a.Cin; ci0 += KC) {
-            __syncthreads();  // previous stage (or tile) fully consumed
-            // Staging issues EVERY global load of the stage before the first use (fixed trip counts, clamped addresses,
-            // predicated results): a load inside an `if` gets its own s_waitcnt in that branch, which made the stage a
-            // chain of dependent round trips (one per 256 elements) instead of one.
-            // Weights of all taps for KC channels.  Packed layout [ci/8][k][ci%8][Mp] (rows contiguous): a tile row is
-            // TM contiguous floats, copied with 16-B loads / ds_write_b128, no transposition
-            constexpr int WN = KT * KC * (TM / 4), WIT = (WN + 255) / 256;
-            float4 wv[WIT];
+        // Weights of all taps for KC channels.  Packed layout [ci/8][k][ci%8][Mp] (rows contiguous): a tile row is
+        // TM contiguous floats, copied with 16-B loads / ds_write_b128, no transposition
+        constexpr int WN = KT * KC * (TM / 4), WIT = (WN + 255) / 256;
+        constexpr int LPC = 256 / KC;
+        constexpr int XJ1 = (VTN / 4 + LPC - 1) / LPC;   // one-tap path: float4 groups of the input tile per thread
+        const int xci = tid / LPC, xl = tid - xci * LPC;
+        float4 wv[WIT];
+        float4 xv1[KT == 1 ? XJ1 : 1];
+        float al = 0.f, ib = 0.f;
+        // Staging issues EVERY global load of a stage before the first use (fixed trip counts, clamped addresses,
+        // predicated results): a load inside an `if` gets its own s_waitcnt in that branch, which made the stage a
+        // chain of dependent round trips (one per 256 elements) instead of one.
+        auto load_w = [&](int ci0) {
 #pragma unroll
             for (int i = 0; i < WIT; i++) {
                 const int idx = tid + i * 256, ic = idx < WN ? idx : 0;
@@ -92,10 +96,33 @@ __global__ void __launch_bounds__(256, MT >= 4 ? 3 : (MT == 3 ? 3 : 4)) conv_ker
             }
             // the input line buffer (causal: columns left of 0 are zero; Snake(0) = 0 so padding commutes).  A thread
             // stays on ONE channel of the stage (LPC lanes per channel), so its Snake parameters are two registers
-            constexpr int LPC = 256 / KC;
-            const int xci = tid / LPC, xl = tid - xci * LPC;
-            float al = 0.f, ib = 0.f;
             if (a.alpha) { al = a.alpha[ci0 + xci]; ib = a.inv_beta[ci0 + xci]; }
+        };
+        auto load_x1 = [&](int ci0) {   // one tap: no halo, the tile's 128 columns start 16-byte aligned
+#pragma unroll
+            for (int j = 0; j < (KT == 1 ? XJ1 : 1); j++) {
+                const int c4 = (xl + j * LPC) * 4, c4c = c4 < VTN ? c4 : 0;
+                const int gl = l0 + c4c, glc = gl < Lcols ? gl : 0;
+                const int bb = a.flat_B > 0 ? glc / a.Lin : 0, l = glc - bb * a.Lin;   // (4 | Lin: a group stays in its chunk)
+                xv1[j] = *(const float4*)(xb + (unsigned)((bb * a.Cin + ci0 + xci) * a.Lin + l));
+            }
+        };
+        // One tap: the stage is short (KC / 2 MFMAs per row tile), so the NEXT stage's operands are requested into
+        // registers before this stage's MFMAs and land under them (2 + 2 float4 per thread at 16 channels); with more
+        // taps the prefetch registers cost a workgroup per CU (tried: 1.6x slower).
+        // (32-channel stages keep the plain form: 16 + 16 more live registers put the 128-row tile 99 registers over)
+        const bool al1 = KT == 1 && (a.Lin & 3) == 0;      // one tap, aligned: 16-byte staging
+        const bool pre1 = al1 && KC <= 16;                  // ... with the next stage prefetched
+        if (pre1) {
+            load_w(0);
+            load_x1(0);
+        }
+        for (int ci0 = 0; ci0 < a.Cin; ci0 += KC) {
+            __syncthreads();  // previous stage (or tile) fully consumed
+            if (!pre1) {
+                load_w(ci0);
+                if (al1) load_x1(ci0);
+            }
             auto store_w = [&]() {
 #pragma unroll
                 for (int i = 0; i < WIT; i++) {
@@ -106,23 +133,14 @@ __global__ void __launch_bounds__(256, MT >= 4 ? 3 : (MT == 3 ? 3 : 4)) conv_ker
                     }
                 }
             };
-            if (KT == 1 && (a.Lin & 3) == 0) {
-                // one tap: no halo, the tile's 128 columns start 16-byte aligned -> 16-byte loads / ds_write_b128
-                constexpr int XJ = (VTN / 4 + LPC - 1) / LPC;
-                float4 xv[XJ];
-#pragma unroll
-                for (int j = 0; j < XJ; j++) {
-                    const int c4 = (xl + j * LPC) * 4, c4c = c4 < VTN ? c4 : 0;
-                    const int gl = l0 + c4c, glc = gl < Lcols ? gl : 0;
-                    const int bb = a.flat_B > 0 ? glc / a.Lin : 0, l = glc - bb * a.Lin;   // (4 | Lin: a group stays in its chunk)
-                    xv[j] = *(const float4*)(xb + (unsigned)((bb * a.Cin + ci0 + xci) * a.Lin + l));
-                }
+            if (al1) {
+                // operands of this stage are in registers (requested a stage ago when prefetching) -> ds_write_b128
                 store_w();
 #pragma unroll
-                for (int j = 0; j < XJ; j++) {
+                for (int j = 0; j < (KT == 1 ? XJ1 : 1); j++) {
                     const int c4 = (xl + j * LPC) * 4;
                     if (c4 < VTN) {
-                        float4 v = xv[j];
+                        float4 v = xv1[j];
                         if (a.alpha) {
                             float sn;
                             sn = __sinf(al * v.x); v.x = v.x + ib * (sn * sn);
@@ -168,6 +186,10 @@ __global__ void __launch_bounds__(256, MT >= 4 ? 3 : (MT == 3 ? 3 : 4)) conv_ker
                 }
             }
             __syncthreads();
+            if (pre1 && ci0 + KC < a.Cin) {   // the next stage's operands: in flight under this stage's MFMAs
+                load_w(ci0 + KC);
+                load_x1(ci0 + KC);
+            }
 #pragma unroll 1
             for (int k = 0; k < KT; k++) {
                 const int off = halo - (KT - 1 - k) * a.dil + w * 32 + (lane & 31);
