@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--no-vocoder", action="store_true", help="time the talker + code-predictor loop only")
     ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 latency leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-longform", action="store_true", help="skip the long-form latency leg (configs[4])")
+    ap.add_argument("--longform-frames", type=int, default=768, help="frames of the long-form leg (768 = 61.4 s of audio)")
     ap.add_argument("--no-timeline", action="store_true",
                     help="skip the in-graph timeline child process (use under rocprofv3: the profiler follows the child, "
                          "whose graph replay it cannot trace); the roofline then comes from the stand-alone launch loop")
@@ -209,6 +211,46 @@ def run_leg(eng, voc, prefixes, n_text, pad, frames, steps, warmup, sync_all):
     dt = time.perf_counter() - t0
     pool.shutdown()
     return dt, float(np.mean(frame_ms)), float(np.mean(prefill_ms)), float(np.mean(voc.ms)) if voc is not None else 0.0
+
+
+def longform_leg(lib, path, voc_path, prefix, n_text, pad, frames):
+    """BASELINE configs[4]: ONE utterance of >= 60 s of audio in latency mode -- prefill, `frames` frame steps, and the
+    vocoder's overlap-crossfade chunk walk over the whole utterance (voc_synthesize_f32 = VocoderServer.synthesize,
+    vocoder_server.py:73-121: 64-frame chunks stepping by 48).  First audio = prefill + the first 64 frames + their
+    chunk.  One untimed pass first (graph capture, LDS attributes)."""
+    from qwen3_tts_axera_russian_amd import hiplib
+    from qwen3_tts_axera_russian_amd.engine import FrameEngine
+    eng = FrameEngine(path, max_batch=1, n_ctx=prefix.shape[0] + frames + 8, max_frames=frames)
+    eng.set_pad_embed(pad)
+    lib.voc_set_exact_fp32(1)
+    h = lib.voc_load(voc_path.encode(), 64, 1)
+    if not h:
+        raise SystemExit("bench.py: voc_load failed (long-form leg)")
+    cap = lib.voc_synthesize_max_samples(h, frames)
+    wav = np.empty(cap, np.float32)
+    first = np.empty((1, 64 * 1920), np.float32)
+    ns = np.zeros(1, np.int32)
+    res = None
+    for timed in (False, True):
+        t0 = time.perf_counter()
+        eng.start([prefix], [n_text], ignore_eos=True, max_frames=frames)
+        assert eng.run(64) == 64
+        c0 = np.ascontiguousarray(eng.codes()[0][:64, 0, :].astype(np.int64))[None]
+        assert lib.voc_decode(h, c0.ctypes.data_as(hiplib.i64p), 1, hiplib.fptr(first)) == 0
+        t_first = time.perf_counter() - t0
+        assert eng.run(frames - 64) == frames - 64
+        codes = np.ascontiguousarray(eng.codes()[0][:frames, 0, :].astype(np.int64))
+        assert lib.voc_synthesize_f32(h, codes.ctypes.data_as(hiplib.i64p), frames, hiplib.fptr(wav), hiplib.iptr(ns)) == 0
+        wall = time.perf_counter() - t0
+        if timed:
+            audio = int(ns[0]) / 24000.0
+            res = {"workload": f"configs[4]: one utterance, {frames} frames = {frames * FRAME_SEC:.1f} s of audio, latency mode "
+                               "(prefill + frame loop + overlap-crossfade chunk walk, exact-fp32 vocoder)",
+                   "frames": frames, "audio_s": round(audio, 2), "wall_s": round(wall, 4), "rtf": round(wall / audio, 5),
+                   "first_audio_ms": round(t_first * 1e3, 2), "frame_loop_ms_per_frame": round(eng.last_run_ms / (frames - 64), 4)}
+    lib.voc_free(h)
+    eng.destroy()
+    return res
 
 
 def kv_bytes_per_step(n_text, frames, cfg):
@@ -491,6 +533,9 @@ def main():
                          "vocoder_ms_per_chunk": round(voc_ms1, 3),
                          "hbm_frac": round(ab1 / (frame_ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         eng1.destroy()
+    if rank == 0 and world == 1 and not a.no_longform and not a.no_vocoder:
+        out["longform"] = longform_leg(lib, path, make_voc_pack(a.cache, a.seed, rank, barrier), prefixes[0], n_text[0], pad,
+                                       a.longform_frames)
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(path, cfg, prefixes[0], n_text[0], pad, a.cpu_frames,
                                            None if a.no_vocoder else make_voc_pack(a.cache, a.seed, rank, barrier))
