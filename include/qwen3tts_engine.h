@@ -79,6 +79,17 @@ float q3e_last_prefill_ms(void* e);
  * utterances hold -1 in column 0.  n_frames_per_utt[b] = frames utterance b really emitted. */
 int q3e_get_codes(void* e, int32_t* out, int max_out_frames, int32_t* n_frames_per_utt);
 
+/* Continuous batching (no counterpart in the reference, whose servers take one request at a time: SURVEY.md 8f2).
+ * q3e_get_done: done[b] = 1 once utterance b has ended (EOS, or its frame budget); frames[b] (may be NULL) = frames it
+ * has emitted.  q3e_refill: put n NEW utterances into the given slots of the running batch (finished or not) without
+ * touching the others: the slots' counters, token history and codes column restart, their prefixes are prefilled
+ * (prefix / n_rows / n_text as for q3e_start, in the order of `slots`), and the next q3e_run continues every slot --
+ * the new ones with the full max_frames budget of q3e_start.  Fetch a finished utterance's codes (q3e_get_codes) BEFORE
+ * refilling its slot.  After a refill q3e_get_codes returns rows up to the longest-running slot's frame count; each
+ * column b holds utterance b's frames from ITS start (row f = its f-th frame).  0 ok / <0 error. */
+int q3e_get_done(void* e, int32_t* done /*[B]*/, int32_t* frames /*[B] or NULL*/);
+int q3e_refill(void* e, int n, const int32_t* slots, const float* prefix, const int32_t* n_rows, const int32_t* n_text);
+
 /* Talker hidden state of every utterance after the last executed step ([B][hidden]). */
 int q3e_get_hidden(void* e, float* out);
 

@@ -72,19 +72,30 @@ class BatchSynthesisServer:
     def synthesize(self, token_ids, max_tokens=None):
         """-> list of (codes int32 [n_frames][16], pcm int16) per utterance."""
         B = len(token_ids)
-        if B == 0 or B > self.max_batch:
-            raise ValueError(f"{B} utterances per request (1..{self.max_batch})")
+        if B == 0:
+            raise ValueError("a request needs at least one utterance")
         max_tokens = min(int(max_tokens or self.max_tokens), self.max_tokens)
         prefixes = [self.front.build_prefix(ids) for ids in token_ids]
         if max(p.shape[0] for p in prefixes) + max_tokens > self.n_ctx:
             raise ValueError("prefix + max_tokens exceed n_ctx")
-        self.eng.start(prefixes, [len(ids) for ids in token_ids], ignore_eos=False, max_frames=max_tokens)
-        self.eng.run(max_tokens)
-        codes, per = self.eng.codes()
+        n_text = [len(ids) for ids in token_ids]
+        if B > self.max_batch:
+            # more utterances than slots: continuous batching -- a finished utterance's slot takes the next one of the
+            # request (q3e_refill), longest expected first (3 frames per text token, llamacpp_talker_server.py:174)
+            order = sorted(range(B), key=lambda i: -n_text[i])
+            got = self.eng.generate_queue([prefixes[i] for i in order], [n_text[i] for i in order], max_tokens)
+            per_utt = [None] * B
+            for k, i in enumerate(order):
+                per_utt[i] = got[k]
+        else:
+            self.eng.start(prefixes, n_text, ignore_eos=False, max_frames=max_tokens)
+            self.eng.run(max_tokens)
+            codes, per = self.eng.codes()
+            per_utt = [codes[:int(per[b]), b, :] for b in range(B)]
         out = []
         for b in range(B):
-            n = int(per[b])
-            c = np.ascontiguousarray(codes[:n, b, :], dtype=np.int32)
+            c = np.ascontiguousarray(per_utt[b], dtype=np.int32)
+            n = c.shape[0]
             pcm = np.zeros(0, np.int16)
             if n > 0:
                 c64 = np.ascontiguousarray(c, dtype=np.int64)
@@ -105,7 +116,7 @@ class BatchSynthesisServer:
         sock.listen(1)
         sock.settimeout(1.0)
         os.chmod(self.socket_path, 0o666)
-        print(f"Batch synthesis server listening on {self.socket_path} (up to {self.max_batch} utterances per request)")
+        print(f"Batch synthesis server listening on {self.socket_path} ({self.max_batch} slots; longer requests run through them by continuous batching)")
         while self._running:
             try:
                 conn, _ = sock.accept()

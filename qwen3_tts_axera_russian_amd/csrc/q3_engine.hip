@@ -34,6 +34,7 @@ struct Engine {
     float* d_pad = nullptr;
     // run state
     int B = 0, ignore_eos = 0, cap_frames = 0, frames_run = 0;
+    int frames_hi = 0;    // frames any slot may have recorded since q3e_start (q3e_refill restarts frames_run, not this)
     GraphExec graph[8];   // one captured frame per chain, replayed on the chain's own stream (own HW queue)
     int graph_B = 0, graph_ignore = -1, graph_cap = -1, graph_chains = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -317,6 +318,100 @@ int q3e_set_pad_embed(void* ee, const float* pad) {
     return 0;
 }
 
+// Ragged prefill of n utterances into the KV slots / output rows ids[0..n) (prefix rows concatenated in that order):
+// utterances are packed into passes of at most prefill_rows rows; every row carries its own (slot, position).  The
+// hidden of each utterance's last row lands in row ids[u] of the post-norm buffers, one group at a time.
+static int prefill_ids(Engine* e, int n, const int* ids, const float* prefix, const int32_t* n_rows, int B_total) {
+    const Model& m = *e->m;
+    const int H = m.cfg.hidden;
+    size_t row_off = 0;
+    int u0 = 0;
+    std::vector<int> slot, pos, tiles, last(n);
+    while (u0 < n) {
+        int u1 = u0, rows = 0;
+        while (u1 < n && rows + n_rows[u1] <= e->prefill_rows) rows += n_rows[u1++];
+        slot.resize(rows);
+        pos.resize(rows);
+        int r = 0;
+        tiles.clear();
+        bool contiguous = true;
+        for (int u = u0; u < u1; u++) {
+            const int b = ids[u];
+            if (u > u0 && b != ids[u - 1] + 1) contiguous = false;
+            for (int i = 0; i < n_rows[u]; i += 16) {      // the utterance's rows as runs of <= 16 positions (attn_tile_kernel)
+                const int nn = n_rows[u] - i < 16 ? n_rows[u] - i : 16;
+                const int t4[4] = {r + i, nn, b, i};
+                tiles.insert(tiles.end(), t4, t4 + 4);
+            }
+            for (int i = 0; i < n_rows[u]; i++, r++) {
+                slot[r] = b;
+                pos[r] = i;
+            }
+            last[u] = r - 1;
+        }
+        Q3_HIP(hipMemcpyAsync(e->wt.rows_in, prefix + row_off * H, sizeof(float) * (size_t)rows * H, hipMemcpyHostToDevice, e->s), -1);
+        Q3_HIP(hipMemcpyAsync(e->d_slot, slot.data(), sizeof(int) * rows, hipMemcpyHostToDevice, e->s), -1);
+        Q3_HIP(hipMemcpyAsync(e->d_pos, pos.data(), sizeof(int) * rows, hipMemcpyHostToDevice, e->s), -1);
+        Q3_HIP(hipMemcpyAsync(e->d_tiles, tiles.data(), sizeof(int) * tiles.size(), hipMemcpyHostToDevice, e->s), -1);
+        if (contiguous) {
+            Q3_HIP(hipMemcpyAsync(e->d_lastrow + ids[u0], last.data() + u0, sizeof(int) * (u1 - u0), hipMemcpyHostToDevice, e->s), -1);
+        } else {
+            for (int u = u0; u < u1; u++)
+                Q3_HIP(hipMemcpyAsync(e->d_lastrow + ids[u], last.data() + u, sizeof(int), hipMemcpyHostToDevice, e->s), -1);
+        }
+        if (launch_ssq_rows(e->s, e->wt.rows_in, e->wt.h, e->wt.ssq, rows, H, e->wt.xh, m.talker.L[0].in_ln)) return -1;
+        RowMap rm;
+        rm.slot = e->d_slot;
+        rm.pos = e->d_pos;
+        rm.same_slot_rows = true;
+        rm.tiles = e->d_tiles;
+        rm.n_tiles = (int)(tiles.size() / 4);
+        if (run_stack(e->s, m, m.talker, e->wt, e->kv_t, rows, rm, 1024)) return -1;
+        // final norm of the last rows of this group into rows ids[u0..u1) of the post-norm buffers
+        for (int u = u0; u < u1; u += contiguous ? (u1 - u0) : 1) {
+            FinalNormArgs f;
+            f.h = e->wt.h;
+            f.ssq = e->wt.ssq;
+            f.ssq_parts = H / 16;
+            f.gamma = m.talker.final_norm;
+            f.eps = m.cfg.eps;
+            f.R = contiguous ? u1 - u0 : 1;
+            f.row0 = ids[u];   // output rows (fragment-ordered buffers are indexed, not offset)
+            f.H = H;
+            f.row_map = e->d_lastrow;
+            f.out_f32 = e->wt.hidden_f32;
+            f.out_f16 = e->wt.hidden_f16;
+            f.out_copy = e->wc.h;
+            f.out_copy_ssq = e->wc.ssq;
+            f.out_copy_xh = e->wc.xh;
+            f.out_copy_gamma = m.cp.L[0].in_ln;
+            // the first frame's code predictor pass reads its position-0 rows where cp_frame expects them; with
+            // parallel chains (rows split over several frame chains) that is the sequential layout, offset 0
+            f.out_copy_row_off = n_chains_eff(e) == 1 ? cp_seed_row0(e->wc, B_total, 0, B_total) : 0;
+            if (launch_final_norm(e->s, f)) return -1;
+        }
+        Q3_HIP(hipStreamSynchronize(e->s), -1);  // host staging vectors are reused by the next group
+        row_off += rows;
+        u0 = u1;
+    }
+    return 0;
+}
+
+// codec head over rows 0..B-1 of the post-norm hidden (rows of running utterances give the logits they already have)
+static int head_all_rows(Engine* e) {
+    const Model& m = *e->m;
+    LinArgs a;
+    a.wp = m.talker_head.wp;
+    a.N = m.cfg.talker_vocab;
+    a.K = m.cfg.hidden;
+    a.M = e->B;
+    a.nt = 1;
+    a.x16 = e->wt.hidden_f16;
+    a.y = e->wt.logits;
+    a.ldy = m.cfg.talker_vocab;
+    return launch_linear(e->s, a, PRO_F16, EPI_STORE);
+}
+
 int q3e_start(void* ee, int B, const float* prefix, const int32_t* n_rows, const int32_t* n_text, int ignore_eos,
               int max_frames) {
     Engine* e = (Engine*)ee;
@@ -324,7 +419,7 @@ int q3e_start(void* ee, int B, const float* prefix, const int32_t* n_rows, const
     const Model& m = *e->m;
     const int H = m.cfg.hidden;
     if (max_frames <= 0 || max_frames > e->max_frames) max_frames = e->max_frames;
-    std::vector<int> pos0(B), last(B);
+    std::vector<int> pos0(B);
     for (int b = 0; b < B; b++) {
         if (n_rows[b] <= 0 || n_rows[b] > e->prefill_rows || n_rows[b] + max_frames > e->n_ctx) {
             Q3_LOG("q3e_start: utterance %d: %d prefix rows + %d frames do not fit n_ctx=%d", b, n_rows[b], max_frames,
@@ -337,6 +432,7 @@ int q3e_start(void* ee, int B, const float* prefix, const int32_t* n_rows, const
     e->ignore_eos = ignore_eos ? 1 : 0;
     e->cap_frames = max_frames;
     e->frames_run = 0;
+    e->frames_hi = 0;
     Q3_HIP(hipMemsetAsync(e->d_npast, 0, sizeof(int) * B, e->s), -1);
     Q3_HIP(hipMemsetAsync(e->d_done, 0, sizeof(int) * B, e->s), -1);
     Q3_HIP(hipMemsetAsync(e->d_nframes, 0, sizeof(int) * B, e->s), -1);
@@ -358,83 +454,12 @@ int q3e_start(void* ee, int B, const float* prefix, const int32_t* n_rows, const
     Q3_HIP(hipMemcpyAsync(e->d_posdec, pos0.data(), sizeof(int) * B, hipMemcpyHostToDevice, e->s), -1);
     Q3_HIP(hipStreamSynchronize(e->s), -1);
     Q3_HIP(hipEventRecord(e->ev0, e->s), -1);
-    // ragged prefill: utterances are packed into passes of at most prefill_rows rows; every row
-    // carries its own (slot, position).  Hidden of each utterance's last row lands in row b of
-    // the post-norm buffers, in utterance order, one group at a time.
-    size_t row_off = 0;
-    int b0 = 0;
-    std::vector<int> slot, pos, tiles;
-    while (b0 < B) {
-        int b1 = b0, rows = 0;
-        while (b1 < B && rows + n_rows[b1] <= e->prefill_rows) rows += n_rows[b1++];
-        slot.resize(rows);
-        pos.resize(rows);
-        int r = 0;
-        tiles.clear();
-        for (int b = b0; b < b1; b++) {
-            for (int i = 0; i < n_rows[b]; i += 16) {      // the utterance's rows as runs of <= 16 positions (attn_tile_kernel)
-                const int n = n_rows[b] - i < 16 ? n_rows[b] - i : 16;
-                const int t4[4] = {r + i, n, b, i};
-                tiles.insert(tiles.end(), t4, t4 + 4);
-            }
-            for (int i = 0; i < n_rows[b]; i++, r++) {
-                slot[r] = b;
-                pos[r] = i;
-            }
-            last[b] = r - 1;
-        }
-        Q3_HIP(hipMemcpyAsync(e->wt.rows_in, prefix + row_off * H, sizeof(float) * (size_t)rows * H, hipMemcpyHostToDevice, e->s), -1);
-        Q3_HIP(hipMemcpyAsync(e->d_slot, slot.data(), sizeof(int) * rows, hipMemcpyHostToDevice, e->s), -1);
-        Q3_HIP(hipMemcpyAsync(e->d_pos, pos.data(), sizeof(int) * rows, hipMemcpyHostToDevice, e->s), -1);
-        Q3_HIP(hipMemcpyAsync(e->d_tiles, tiles.data(), sizeof(int) * tiles.size(), hipMemcpyHostToDevice, e->s), -1);
-        Q3_HIP(hipMemcpyAsync(e->d_lastrow + b0, last.data() + b0, sizeof(int) * (b1 - b0), hipMemcpyHostToDevice, e->s), -1);
-        if (launch_ssq_rows(e->s, e->wt.rows_in, e->wt.h, e->wt.ssq, rows, H, e->wt.xh, m.talker.L[0].in_ln)) return -1;
-        RowMap rm;
-        rm.slot = e->d_slot;
-        rm.pos = e->d_pos;
-        rm.same_slot_rows = true;
-        rm.tiles = e->d_tiles;
-        rm.n_tiles = (int)(tiles.size() / 4);
-        if (run_stack(e->s, m, m.talker, e->wt, e->kv_t, rows, rm, 1024)) return -1;
-        // final norm of the last rows of this group into rows b0..b1 of the post-norm buffers
-        {
-            FinalNormArgs f;
-            f.h = e->wt.h;
-            f.ssq = e->wt.ssq;
-            f.ssq_parts = H / 16;
-            f.gamma = m.talker.final_norm;
-            f.eps = m.cfg.eps;
-            f.R = b1 - b0;
-            f.row0 = b0;   // output rows b0..b1-1 (fragment-ordered buffers are indexed, not offset)
-            f.H = H;
-            f.row_map = e->d_lastrow;
-            f.out_f32 = e->wt.hidden_f32;
-            f.out_f16 = e->wt.hidden_f16;
-            f.out_copy = e->wc.h;
-            f.out_copy_ssq = e->wc.ssq;
-            f.out_copy_xh = e->wc.xh;
-            f.out_copy_gamma = m.cp.L[0].in_ln;
-            // the first frame's code predictor pass reads its position-0 rows where cp_frame expects them; with
-            // parallel chains (rows split over several frame chains) that is the sequential layout, offset 0
-            f.out_copy_row_off = n_chains_eff(e) == 1 ? cp_seed_row0(e->wc, B, 0, B) : 0;
-            if (launch_final_norm(e->s, f)) return -1;
-        }
-        Q3_HIP(hipStreamSynchronize(e->s), -1);  // host staging vectors are reused by the next group
-        row_off += rows;
-        b0 = b1;
-    }
     {
-        LinArgs a;
-        a.wp = m.talker_head.wp;
-        a.N = m.cfg.talker_vocab;
-        a.K = H;
-        a.M = B;
-        a.nt = 1;
-        a.x16 = e->wt.hidden_f16;
-        a.y = e->wt.logits;
-        a.ldy = m.cfg.talker_vocab;
-        if (launch_linear(e->s, a, PRO_F16, EPI_STORE)) return -1;
+        std::vector<int> ids(B);
+        for (int b = 0; b < B; b++) ids[b] = b;
+        if (prefill_ids(e, B, ids.data(), prefix, n_rows, B)) return -1;
     }
+    if (head_all_rows(e)) return -1;
     Q3_HIP(hipEventRecord(e->ev1, e->s), -1);
     Q3_HIP(hipStreamSynchronize(e->s), -1);
     hipEventElapsedTime(&e->last_prefill_ms, e->ev0, e->ev1);
@@ -507,6 +532,7 @@ int q3e_run(void* ee, int n_frames) {
     Q3_HIP(hipStreamSynchronize(e->s), -1);
     hipEventElapsedTime(&e->last_run_ms, e->ev0, e->ev1);
     e->frames_run += done_frames;
+    e->frames_hi += done_frames;
     return done_frames;
 }
 
@@ -517,13 +543,66 @@ float q3e_last_prefill_ms(void* ee) { return ee ? ((Engine*)ee)->last_prefill_ms
 int q3e_get_codes(void* ee, int32_t* out, int max_out_frames, int32_t* n_frames_per_utt) {
     Engine* e = (Engine*)ee;
     if (!e || !out || e->B <= 0) return -1;
-    int nf = e->frames_run < e->max_frames ? e->frames_run : e->max_frames;
+    int nf = e->frames_hi < e->max_frames ? e->frames_hi : e->max_frames;
     if (nf > max_out_frames) nf = max_out_frames;
     Q3_HIP(hipMemcpy(out, e->d_codes, sizeof(int) * 16 * (size_t)e->B * nf, hipMemcpyDeviceToHost), -1);
     if (n_frames_per_utt) {
         Q3_HIP(hipMemcpy(n_frames_per_utt, e->d_npast, sizeof(int) * e->B, hipMemcpyDeviceToHost), -1);
     }
     return nf;
+}
+
+int q3e_get_done(void* ee, int32_t* done, int32_t* frames) {
+    Engine* e = (Engine*)ee;
+    if (!e || !done || e->B <= 0) return -1;
+    Q3_HIP(hipMemcpy(done, e->d_done, sizeof(int) * e->B, hipMemcpyDeviceToHost), -1);
+    if (frames) Q3_HIP(hipMemcpy(frames, e->d_npast, sizeof(int) * e->B, hipMemcpyDeviceToHost), -1);
+    return 0;
+}
+
+int q3e_refill(void* ee, int n, const int32_t* slots, const float* prefix, const int32_t* n_rows, const int32_t* n_text) {
+    Engine* e = (Engine*)ee;
+    if (!e || e->B <= 0 || n <= 0 || n > e->B || !slots || !prefix || !n_rows || !n_text) return -1;
+    if (e->forced_on) {
+        Q3_LOG("q3e_refill: a teacher-forced batch cannot be refilled");
+        return -1;
+    }
+    std::vector<int> ids(slots, slots + n), seen(e->B, 0);
+    for (int u = 0; u < n; u++) {
+        const int b = ids[u];
+        if (b < 0 || b >= e->B || seen[b]++) {
+            Q3_LOG("q3e_refill: slot %d is out of range or listed twice (batch of %d)", b, e->B);
+            return -1;
+        }
+        if (n_rows[u] <= 0 || n_rows[u] > e->prefill_rows || n_rows[u] + e->cap_frames > e->n_ctx) {
+            Q3_LOG("q3e_refill: utterance %d: %d prefix rows + %d frames do not fit n_ctx=%d", u, n_rows[u], e->cap_frames, e->n_ctx);
+            return -1;
+        }
+    }
+    Q3_HIP(hipStreamSynchronize(e->s), -1);
+    Q3_HIP(hipEventRecord(e->ev0, e->s), -1);
+    // per-slot state back to "just started": counters, the emitted-token ring, the slot's column of the codes array
+    const int zero = 0;
+    for (int u = 0; u < n; u++) {
+        const int b = ids[u];
+        Q3_HIP(hipMemsetAsync(e->d_npast + b, 0, sizeof(int), e->s), -1);
+        Q3_HIP(hipMemsetAsync(e->d_done + b, 0, sizeof(int), e->s), -1);
+        Q3_HIP(hipMemsetAsync(e->d_nframes + b, 0, sizeof(int), e->s), -1);
+        Q3_HIP(hipMemsetAsync(e->d_past + 32 * b, 0, sizeof(int) * 32, e->s), -1);
+        Q3_HIP(hipMemset2DAsync(e->d_codes + 16 * (size_t)b, sizeof(int) * 16 * (size_t)e->B, 0xff, sizeof(int) * 16, e->max_frames, e->s), -1);
+        Q3_HIP(hipMemcpyAsync(e->d_ntext + b, n_text + u, sizeof(int), hipMemcpyHostToDevice, e->s), -1);
+        Q3_HIP(hipMemcpyAsync(e->d_pos0 + b, n_rows + u, sizeof(int), hipMemcpyHostToDevice, e->s), -1);
+        Q3_HIP(hipMemcpyAsync(e->d_posdec + b, n_rows + u, sizeof(int), hipMemcpyHostToDevice, e->s), -1);
+    }
+    (void)zero;
+    Q3_HIP(hipStreamSynchronize(e->s), -1);
+    if (prefill_ids(e, n, ids.data(), prefix, n_rows, e->B)) return -1;
+    if (head_all_rows(e)) return -1;
+    Q3_HIP(hipEventRecord(e->ev1, e->s), -1);
+    Q3_HIP(hipStreamSynchronize(e->s), -1);
+    hipEventElapsedTime(&e->last_prefill_ms, e->ev0, e->ev1);
+    e->frames_run = 0;   // the new utterances have their whole frame budget; running ones stop at theirs on the device
+    return 0;
 }
 
 int q3e_get_hidden(void* ee, float* out) {

@@ -82,6 +82,60 @@ class FrameEngine:
             raise RuntimeError("q3e_get_codes failed")
         return out[:nf], per
 
+    def done(self):
+        """-> (done[B] bool: the utterance has ended (EOS or its frame budget), frames emitted per utterance)."""
+        d = np.zeros(self.B, np.int32)
+        per = np.zeros(self.B, np.int32)
+        if self._lib.q3e_get_done(self.h, hiplib.iptr(d), hiplib.iptr(per)) != 0:
+            raise RuntimeError("q3e_get_done failed")
+        return d.astype(bool), per
+
+    def refill(self, slots, prefixes, n_text):
+        """Continuous batching: put new utterances into `slots` of the running batch (q3e_refill); the other slots go on
+        untouched.  Fetch the codes of a finished utterance before refilling its slot."""
+        slots = np.ascontiguousarray(np.asarray(slots, np.int32))
+        assert len(slots) == len(prefixes) == len(n_text) and len(slots) > 0
+        cat = np.ascontiguousarray(np.concatenate([np.asarray(p, np.float32) for p in prefixes], axis=0))
+        n_rows = np.array([p.shape[0] for p in prefixes], np.int32)
+        nt = np.ascontiguousarray(np.asarray(n_text, np.int32))
+        rc = self._lib.q3e_refill(self.h, len(slots), hiplib.iptr(slots), hiplib.fptr(cat), hiplib.iptr(n_rows), hiplib.iptr(nt))
+        if rc != 0:
+            raise RuntimeError(f"q3e_refill failed: {rc}")
+
+    def generate_queue(self, prefixes, n_text, max_frames, ignore_eos=False, check_every=8, on_done=None):
+        """Continuous batching over a queue of utterances: the first max_batch of them start together; every
+        `check_every` frames the finished slots hand over their codes and take the next utterance of the queue
+        (q3e_refill), so the frame loop never steps a batch of mostly finished rows.  -> list of int32 [frames][16] in
+        queue order.  on_done(index, codes) is called as each utterance finishes (e.g. to hand it to the vocoder)."""
+        n = len(prefixes)
+        assert n == len(n_text) and n > 0
+        B = min(self.max_batch, n)
+        out = [None] * n
+        owner = list(range(B))                    # queue index of the utterance in each slot
+        nxt = B
+        self.start(prefixes[:B], n_text[:B], ignore_eos=ignore_eos, max_frames=max_frames)
+        while any(o is not None for o in owner):
+            self.run(check_every)
+            done, per = self.done()
+            fin = [b for b in range(B) if owner[b] is not None and done[b]]
+            if not fin:
+                continue
+            codes, _ = self.codes()
+            for b in fin:
+                res = np.ascontiguousarray(codes[:int(per[b]), b, :])
+                out[owner[b]] = res
+                if on_done is not None:
+                    on_done(owner[b], res)
+                owner[b] = None
+            take = [b for b in fin if nxt + fin.index(b) < n]
+            if take:
+                idx = [nxt + i for i in range(len(take))]
+                self.refill(take, [prefixes[i] for i in idx], [n_text[i] for i in idx])
+                for b, i in zip(take, idx):
+                    owner[b] = i
+                nxt += len(take)
+        return out
+
     def hidden(self):
         out = np.empty((self.B, 1024), np.float32)
         if self._lib.q3e_get_hidden(self.h, hiplib.fptr(out)) != 0:

@@ -70,6 +70,8 @@ def load(path: str | None = None):
     _sig(lib, "q3e_last_run_ms", c_float, [c_void_p])
     _sig(lib, "q3e_last_prefill_ms", c_float, [c_void_p])
     _sig(lib, "q3e_get_codes", c_int, [c_void_p, i32p, c_int, i32p])
+    _sig(lib, "q3e_get_done", c_int, [c_void_p, i32p, i32p])
+    _sig(lib, "q3e_refill", c_int, [c_void_p, c_int, i32p, f32p, i32p, i32p])
     _sig(lib, "q3e_get_hidden", c_int, [c_void_p, f32p])
     _sig(lib, "q3e_step_weight_bytes", ctypes.c_double, [c_void_p])
     # include/qwen3tts_voc.h

@@ -277,3 +277,75 @@ def test_teacher_forced_two_layer_long_run_every_decision_graded(gpu_lib, world)
     print(f"2-layer, 24 frames x 5: {same}/{n} identical; gaps of the others:", sorted(round(m, 6) for *_, m in flips))
     assert n == 5 * F * 16 and all(m < NEAR_TIE for *_, m in flips) and len(flips) <= 0.02 * n
     eng.destroy()
+
+
+def test_refill_puts_new_utterances_into_finished_slots_and_leaves_the_others_alone(gpu_lib, world):
+    """Continuous batching (q3e_refill): utterance 2 ends early (EOS boost); its slot gets a new utterance while 0 and 1
+    keep running.  Every stream -- the two that ran through the refill and the new one from ITS first frame -- is graded
+    against the CPU pipeline like a batch started from scratch (_compare: exact up to an oracle near-tie), and the
+    frames slots 0 / 1 had emitted before the refill are bit-identical after it."""
+    path, cfg, tensors, cpu = world
+    rng = np.random.default_rng(73)
+    prefixes = _prefixes(rng, [12, 21, 17, 15])
+    n_text = [30, 12, 3, 30]
+    pad = (0.05 * rng.standard_normal(1024)).astype(np.float32)
+    cap = 24
+    eng = FrameEngine(path, max_batch=4, n_ctx=96, max_frames=32)
+    eng.set_pad_embed(pad)
+    eng.start(prefixes[:3], n_text[:3], ignore_eos=False, max_frames=cap)
+    assert eng.run(16) == 16
+    done, per = eng.done()
+    before, per_before = eng.codes()
+    before = before.copy()
+    assert done[2] and not done[0] and not done[1], (done, per)      # the EOS boost ended utterance 2 early
+    eng.refill([2], [prefixes[3]], [n_text[3]])
+    done, per = eng.done()
+    assert not done[2] and int(per[2]) == 0 and int(per[0]) == 16
+    ran = eng.run(cap)
+    after, per_after = eng.codes()
+    assert 8 <= ran <= cap
+    np.testing.assert_array_equal(after[:16, :2], before[:16, :2])    # the running slots were not disturbed
+    refs, margins = [], []
+    for b, u in enumerate((0, 1, 3)):                                 # slot 2 now holds utterance 3
+        fr, mm = cpu.generate(prefixes[u], n_text[u], pad, cap, want_margins=True)
+        refs.append(fr)
+        margins.append(mm)
+    stats = _compare(after, per_after, refs, margins)
+    print("frames per slot after the refill:", [int(x) for x in per_after], "ref:", [len(r) for r in refs], stats, "ran", ran)
+    assert sum(st == "exact" for st in stats) >= 2, stats
+    assert int(per_after[2]) >= 8                                     # the new utterance got its own frame budget
+    # errors: a slot twice, out of range, a prefix that cannot fit
+    with pytest.raises(RuntimeError):
+        eng.refill([1, 1], [prefixes[0], prefixes[1]], [5, 5])
+    with pytest.raises(RuntimeError):
+        eng.refill([3], [prefixes[0]], [5])
+    with pytest.raises(RuntimeError):
+        eng.refill([0], [np.zeros((90, 1024), np.float32)], [5])
+    eng.destroy()
+
+
+def test_generate_queue_keeps_every_slot_busy_and_matches_per_utterance_runs(gpu_lib, world):
+    """FrameEngine.generate_queue: 7 utterances of different lengths through 3 slots; every stream is graded against the
+    CPU pipeline like a batch of its own, and fewer frame steps run than three-at-a-time batches would need."""
+    path, cfg, tensors, cpu = world
+    rng = np.random.default_rng(74)
+    lens = [12, 21, 17, 15, 9, 26, 14]
+    n_text = [6, 3, 8, 2, 7, 4, 5]           # adaptive EOS: budgets of roughly 3 x n_text frames
+    prefixes = _prefixes(rng, lens)
+    pad = (0.05 * rng.standard_normal(1024)).astype(np.float32)
+    cap = 28
+    eng = FrameEngine(path, max_batch=3, n_ctx=96, max_frames=32)
+    eng.set_pad_embed(pad)
+    finished = []
+    got = eng.generate_queue(prefixes, n_text, cap, check_every=4, on_done=lambda i, c: finished.append(i))
+    assert sorted(finished) == list(range(7)) and all(g is not None for g in got)
+    stats = []
+    for i in range(7):
+        fr, mm = cpu.generate(prefixes[i], n_text[i], pad, cap, want_margins=True)
+        codes = np.full((cap, 1, 16), -1, np.int32)
+        codes[:len(got[i]), 0] = got[i]
+        stats += _compare(codes, np.array([len(got[i])]), [fr], [mm])   # asserts: a divergence only at an oracle near-tie
+    print("queue order of completion:", finished, "frames:", [len(g) for g in got], stats)
+    assert sum(st == "exact" for st in stats) >= 3, stats
+    assert len({len(g) for g in got}) > 2    # the utterances really had different lengths
+    eng.destroy()

@@ -89,7 +89,8 @@ def test_batch_server_matches_single_utterance_path(gpu_lib, packs, tmp_path):
     for every utterance, the codec ids of the fused engine run on the same batch and the PCM of the vocoder's chunk
     walk over those ids -- ragged lengths and an empty text included (utterances of one batch share the ragged
     prefill, whose tile shapes depend on the total row count, so ids are compared batch against the same batch); a
-    malformed request gets the error sentinel and the server keeps serving."""
+    request with more utterances than slots is served by continuous batching; a malformed request gets the error
+    sentinel and the server keeps serving."""
     import socket
     import struct
     from qwen3_tts_axera_russian_amd import batch_server as bs
@@ -121,10 +122,29 @@ def test_batch_server_matches_single_utterance_path(gpu_lib, packs, tmp_path):
         np.testing.assert_array_equal(pcm, vs.synthesize_int16(codes.astype(np.int64)))
         assert len(pcm) >= n * 1920
     assert len({int(x) for x in per}) > 1          # the utterances really ended at different frames
-    # too many utterances -> error sentinel; the next request is served
+    # more utterances than slots: continuous batching (q3e_refill) -- every utterance comes back, in request order,
+    # with the codes it gets in a batch of its own (slots are independent; greedy decode)
+    many = [reqs[0], reqs[1], reqs[3], [9, 8, 7, 6, 5], reqs[1], [301, 302, 303]]
+    res6 = bs.synthesize_batch(sock, token_ids=many)
+    assert len(res6) == 6
+    # (a row's f32 sums depend on how many rows share its pass -- the split of K over waves follows the row count -- so
+    # equality with the batch-of-4 codes holds only up to near-tie flips; the reference here is the same queue run on an
+    # engine of its own: same order (longest first), same refills, bit-identical)
+    eng = FrameEngine(main, max_batch=4, n_ctx=128, max_frames=70)
+    eng.set_pad_embed(srv.front.tts_pad_embed)
+    order = sorted(range(6), key=lambda i: -len(many[i]))
+    q = eng.generate_queue([srv.front.build_prefix(many[i]) for i in order], [len(many[i]) for i in order], 70)
+    eng.destroy()
+    for k, i in enumerate(order):
+        np.testing.assert_array_equal(res6[i][0], q[k])
+        np.testing.assert_array_equal(res6[i][1], vs.synthesize_int16(q[k].astype(np.int64)))
+    assert abs(len(res6[0][0]) - len(res[0][0])) <= 8 and abs(len(res6[2][0]) - len(res[3][0])) <= 8
+    for codes, pcm in res6:
+        assert codes.shape[0] >= 1 and (codes >= 0).all() and (codes < 2048).all() and len(pcm) >= codes.shape[0] * 1920
+    # an empty request -> error sentinel; the next request is served
     s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
     s.connect(sock)
-    s.sendall(bs.pack_batch_request(token_ids=[[1]] * 5))
+    s.sendall(bs.pack_batch_request(token_ids=[]))
     assert struct.unpack("<i", s.recv(4))[0] == -2
     s.close()
     assert len(bs.synthesize_batch(sock, token_ids=[[9, 8, 7]])) == 1
