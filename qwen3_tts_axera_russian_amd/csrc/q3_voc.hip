@@ -333,11 +333,77 @@ static int launch_conv_mt(hipStream_t s, const ConvArgs& a, int B) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// The decoder's last conv: C channels -> ONE output row (7 taps, Snake on the input, clamp).  On the MFMA it is a
+// 32-row tile with one live row (1.6 ms per 32 chunks at 0.97 TB/s); it is a dot product per sample and HBM-bound:
+// each thread owns 8 consecutive samples, walks the channels, reads the 14 inputs they need as four aligned float4
+// (neighbouring threads' overlap comes from L1), applies Snake once per input and accumulates the 7 taps in f32.
+// Weights are read from conv_kernel's packed layout ([C/8][7][8][Mp], row 0) with wave-uniform (scalar) loads.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) conv_out1_kernel(ConvArgs a) {
+    const int b = blockIdx.y;
+    const int l0 = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (l0 >= a.Lin) return;
+    const float* xb = a.x + (size_t)b * a.Cin * a.Lin;
+    float acc[8];
+    const float b0 = a.bias ? a.bias[0] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = b0;
+    for (int c = 0; c < a.Cin; c++) {
+        const float* xr = xb + (size_t)c * a.Lin;
+        float v[16];   // columns l0 - 8 .. l0 + 7
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int l = l0 - 8 + 4 * q;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (l >= 0 && l + 3 < a.Lin) t = *(const float4*)(xr + l);
+            else {
+                if (l >= 0 && l < a.Lin) t.x = xr[l];
+                if (l + 1 >= 0 && l + 1 < a.Lin) t.y = xr[l + 1];
+                if (l + 2 >= 0 && l + 2 < a.Lin) t.z = xr[l + 2];
+                if (l + 3 >= 0 && l + 3 < a.Lin) t.w = xr[l + 3];
+            }
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+        if (a.alpha) {   // Snake(0) = 0: the causal zero padding commutes with it
+            const float al = a.alpha[c], ib = a.inv_beta[c];
+#pragma unroll
+            for (int i = 2; i < 16; i++) {
+                const float sn = __sinf(al * v[i]);
+                v[i] = v[i] + ib * (sn * sn);
+            }
+        }
+        const float* wc = a.wk + (size_t)((c >> 3) * 7 * 8 + (c & 7)) * a.Mp;   // tap k: + k * 8 * Mp
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            const float wv = wc[(size_t)k * 8 * a.Mp];
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j] = fmaf(wv, v[2 + j + k], acc[j]);   // tap k reads column l - (6 - k)
+        }
+    }
+    float* yb = a.y + (size_t)b * a.Lin;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        float o = acc[j];
+        if (a.clamp) o = fminf(fmaxf(o, -1.f), 1.f);
+        if (l0 + j < a.Lin) yb[l0 + j] = o;
+    }
+}
+
 static int launch_conv(hipStream_t s, const ConvArgs& a, int B) {
     const int c = a.Cin;
     if (c % 8) {
         Q3_LOG("voc conv: Cin=%d is not a multiple of 8", c);
         return -1;
+    }
+    static const int out1 = getenv("Q3_VOC_OUT1") ? atoi(getenv("Q3_VOC_OUT1")) : 1;
+    if (out1 && a.M == 1 && a.K == 7 && a.dil == 1 && a.stride == 1 && !a.res && !a.gelu && (a.Lin & 3) == 0 &&
+        (size_t)B * c * a.Lin < ((size_t)1 << 31)) {
+        ConvArgs k = a;
+        k.Mp = 4;
+        hipLaunchKernelGGL(conv_out1_kernel, dim3((a.Lin + 2047) / 2048, B), dim3(256), 0, s, k);
+        Q3_HIP(hipGetLastError(), -1);
+        return 0;
     }
     // few taps: deeper channel stages keep enough MFMAs between barriers
     // one / two taps: 32-channel stages where the activation is short (few tiles: fewer barriers per tile), 16-channel
