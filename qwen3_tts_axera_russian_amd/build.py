@@ -141,6 +141,11 @@ def build(force: bool = False, verbose: bool = False, timeline: bool = False) ->
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
         check_spills(out, verbose)
+        # an existing diagnostic (timeline) build must not go stale: bench.py's in-graph launch durations come from it,
+        # and it must export every symbol hiplib declares
+        tl_out = os.path.join(LIB, "libqwen3tts_tl.so")
+        if os.path.exists(tl_out) and not _newer(tl_out, srcs + hdrs):
+            build(force=force, verbose=verbose, timeline=True)
         alias = os.path.join(LIB, "llama_wrapper.so")
         if not os.path.exists(alias) or os.path.getmtime(alias) < os.path.getmtime(out):
             shutil.copyfile(out, alias)
