@@ -582,7 +582,6 @@ int q3e_refill(void* ee, int n, const int32_t* slots, const float* prefix, const
     Q3_HIP(hipStreamSynchronize(e->s), -1);
     Q3_HIP(hipEventRecord(e->ev0, e->s), -1);
     // per-slot state back to "just started": counters, the emitted-token ring, the slot's column of the codes array
-    const int zero = 0;
     for (int u = 0; u < n; u++) {
         const int b = ids[u];
         Q3_HIP(hipMemsetAsync(e->d_npast + b, 0, sizeof(int), e->s), -1);
@@ -594,7 +593,6 @@ int q3e_refill(void* ee, int n, const int32_t* slots, const float* prefix, const
         Q3_HIP(hipMemcpyAsync(e->d_pos0 + b, n_rows + u, sizeof(int), hipMemcpyHostToDevice, e->s), -1);
         Q3_HIP(hipMemcpyAsync(e->d_posdec + b, n_rows + u, sizeof(int), hipMemcpyHostToDevice, e->s), -1);
     }
-    (void)zero;
     Q3_HIP(hipStreamSynchronize(e->s), -1);
     if (prefill_ids(e, n, ids.data(), prefix, n_rows, e->B)) return -1;
     if (head_all_rows(e)) return -1;
