@@ -1138,11 +1138,27 @@ __global__ void __launch_bounds__(1024) attn_kernel(AttnArgs a) {
 constexpr int ATTN_SHORT_MAX_T = 15;
 static int g_attn_short = 1;
 int set_attn_short(int on) { g_attn_short = on; return 0; }
-__global__ void __launch_bounds__(256) attn_short_kernel(AttnArgs a) {
+// The leading arguments are what the first loads (the row's q / k / v, the norm weights, the RoPE row) need: 16 dwords that
+// arrive in SGPRs at wave launch (-amdgpu-kernarg-preload-count=16, like linear_kernel); the rest of the struct is fetched
+// in one batch under those loads' latency instead of in front of them.
+__global__ void __launch_bounds__(256)
+    attn_short_kernel(float* __restrict__ p_qkv, int p_ld, int p_row0, int p_n_heads, int p_n_kv,
+                      const float* __restrict__ p_q_norm, const float* __restrict__ p_k_norm,
+                      const float* __restrict__ p_rope_cos, const float* __restrict__ p_rope_sin, int p_pos_base,
+                      int p_slot_base, AttnArgs a) {
     constexpr int D = 128, NE = ATTN_SHORT_MAX_T + 1;   // entries: <= 15 cached rows + the appended token
-    Q3_FETCH_ARGS("s"(a.qkv), "s"(a.ld), "s"(a.row0), "s"(a.q_norm), "s"(a.k_norm), "s"(a.eps), "s"(a.rope_cos), "s"(a.rope_sin),
-                  "s"(a.slot), "s"(a.slot_base), "s"(a.slot_stride), "s"(a.pos_base), "s"(a.kc), "s"(a.vc), "s"(a.n_ctx),
-                  "s"(a.n_kv), "s"(a.n_heads), "s"(a.out), "s"(a.scale));
+    a.qkv = p_qkv;
+    a.ld = p_ld;
+    a.row0 = p_row0;
+    a.n_heads = p_n_heads;
+    a.n_kv = p_n_kv;
+    a.q_norm = p_q_norm;
+    a.k_norm = p_k_norm;
+    a.rope_cos = p_rope_cos;
+    a.rope_sin = p_rope_sin;
+    a.pos_base = p_pos_base;
+    a.slot_base = p_slot_base;
+    Q3_FETCH_ARGS("s"(a.eps), "s"(a.slot), "s"(a.slot_stride), "s"(a.kc), "s"(a.vc), "s"(a.n_ctx), "s"(a.out), "s"(a.scale));
     Q3_TL(33);
     const int r = a.row0 + blockIdx.x, g = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1475,7 +1491,8 @@ int launch_attn(hipStream_t s, const AttnArgs& a, int mode) {
         a.pos_base <= ATTN_SHORT_MAX_T && a.pos_base < a.n_ctx) {
         AttnArgs a3 = a;
         a3.tl_node = tl_next_node();
-        hipLaunchKernelGGL(attn_short_kernel, dim3(a.R, a.n_kv), dim3(256), 0, s, a3);
+        hipLaunchKernelGGL(attn_short_kernel, dim3(a.R, a.n_kv), dim3(256), 0, s, a3.qkv, a3.ld, a3.row0, a3.n_heads, a3.n_kv,
+                           a3.q_norm, a3.k_norm, a3.rope_cos, a3.rope_sin, a3.pos_base, a3.slot_base, a3);
         Q3_HIP(hipGetLastError(), -1);
         return 0;
     }
