@@ -405,13 +405,12 @@ static int launch_conv(hipStream_t s, const ConvArgs& a, int B) {
         Q3_HIP(hipGetLastError(), -1);
         return 0;
     }
-    // few taps: deeper channel stages keep enough MFMAs between barriers
-    // one / two taps: 32-channel stages where the activation is short (few tiles: fewer barriers per tile), 16-channel
-    // stages on the long ones (the 32-channel variants of the 128-row tile spill 27-35 registers; measured at 32 chunks:
-    // 384 -> 384 k1 1.74 -> 1.44 ms, 768 -> 768 k1 1.06 -> 0.94)
-    static const int kc_max = getenv("Q3_VOC_KC_MAX") ? atoi(getenv("Q3_VOC_KC_MAX")) : 0;
-    const bool long_act = (long)a.Lin * B >= 32768;
-    if ((kc_max ? kc_max < 32 : long_act) && c % 16 == 0 && (a.K == 1 || a.K == 2)) return a.K == 1 ? launch_conv_mt<1, 16>(s, a, B) : launch_conv_mt<2, 16>(s, a, B);
+    // one / two taps: 16-channel stages (the one-tap form prefetches the next stage's operands into registers; the
+    // 32-channel variants of the 128-row tile spill 27-35 registers).  Measured at 32 chunks: 384 -> 384 k1 1.74 -> 1.28 ms,
+    // 768 -> 768 k1 1.06 -> 0.84, the ConvNeXt 1024 -> 4096 convs 0.39 / 0.74 -> 0.35 / 0.64; Q3_VOC_KC_MAX=32 restores
+    // the 32-channel stages (channel counts that are no multiple of 16 take them or the 8-channel ones anyway).
+    static const int kc_max = getenv("Q3_VOC_KC_MAX") ? atoi(getenv("Q3_VOC_KC_MAX")) : 16;
+    if (kc_max < 32 && c % 16 == 0 && (a.K == 1 || a.K == 2)) return a.K == 1 ? launch_conv_mt<1, 16>(s, a, B) : launch_conv_mt<2, 16>(s, a, B);
     switch (a.K) {
         case 1: return c % 32 == 0 ? launch_conv_mt<1, 32>(s, a, B) : c % 16 == 0 ? launch_conv_mt<1, 16>(s, a, B) : launch_conv_mt<1, 8>(s, a, B);
         case 2: return c % 32 == 0 ? launch_conv_mt<2, 32>(s, a, B) : c % 16 == 0 ? launch_conv_mt<2, 16>(s, a, B) : launch_conv_mt<2, 8>(s, a, B);
