@@ -159,11 +159,11 @@ class Vocoder:
         if not self.h:
             raise SystemExit("bench.py: voc_load failed")
         self.chunk, self.spt = lib.voc_chunk_tokens(self.h), lib.voc_samples_per_token(self.h)
-        self.out = np.empty((max_batch, self.chunk * self.spt), np.float32)
+        self.out = np.empty((max_batch, lib.voc_chunk_samples(self.h)), np.float32)   # the model's output rows (<= chunk * spt)
         self.ms = []
 
     def decode(self, codes_fb16):
-        """codes [F][B][16] int32 from the engine -> waveform [B][F*1920]."""
+        """codes [F][B][16] int32 from the engine -> waveform [B][voc_chunk_samples]."""
         c = np.ascontiguousarray(np.transpose(codes_fb16, (1, 0, 2)).astype(np.int64))
         B = c.shape[0]
         rc = self.lib.voc_decode(self.h, c.ctypes.data_as(self.hl.i64p), B, self.hl.fptr(self.out))
@@ -228,7 +228,7 @@ def longform_leg(lib, path, voc_path, prefix, n_text, pad, frames):
         raise SystemExit("bench.py: voc_load failed (long-form leg)")
     cap = lib.voc_synthesize_max_samples(h, frames)
     wav = np.empty(cap, np.float32)
-    first = np.empty((1, 64 * 1920), np.float32)
+    first = np.empty((1, lib.voc_chunk_samples(h)), np.float32)
     ns = np.zeros(1, np.int32)
     res = None
     for timed in (False, True):
@@ -330,7 +330,7 @@ def cpu_baseline(path, cfg, prefix, n_text, pad, frames, voc_path=None):
         t1 = time.perf_counter()
         wav = voc_reference(vt, codes)
         dv = time.perf_counter() - t1
-        assert wav.shape == (1, 64 * 1920)
+        assert wav.shape[0] == 1 and wav.shape[1] <= 64 * 1920
         res["vocoder_s_per_chunk"] = round(dv, 2)
         res["rtf_with_vocoder"] = round((dt / frames * 64 + dv) / (64 * FRAME_SEC), 3)
         res["value_with_vocoder"] = round(64 / (dt / frames * 64 + dv), 3)

@@ -10,7 +10,13 @@
  *
  * The decoder's layer list is NOT in the reference: the library executes
  * the op table stored in the weight container (`voc.program`, DESIGN.md "Vocoder program"), so a
- * real checkpoint only needs converting, not a rebuild.
+ * real checkpoint only needs converting, not a rebuild.  The table's semantics are pinned to the
+ * importable implementation of the decoder family (transformers' Qwen3OmniMoeCode2Wav + Mimi's split
+ * RVQ: tests/golden/make_code2wav_golden.py).  That family's transposed convs trim kernel - stride
+ * samples at BOTH ends, so a decode of T frames returns fewer than T * 1920 samples (64 frames ->
+ * 122 325): like the ONNX model's output tensor, voc_decode's rows are voc_chunk_samples() long, and
+ * the slices the reference takes of them (`audio[:n * 1920]`, vocoder_server.py:81,98-99) follow
+ * numpy's rule -- as long as what is there.
  *
  * Caller-owned host buffers, synchronous, one caller thread per handle, no CPU fallback.
  */
@@ -31,14 +37,16 @@ extern "C" {
 void* voc_load(const char* weights, int chunk_tokens, int max_batch);
 void voc_free(void* v);
 int voc_chunk_tokens(void* v);
-int voc_samples_per_token(void* v);
+int voc_samples_per_token(void* v);   /* decoder.total_upsample (export_vocoder_traced.py:46): the product of the strides */
+int voc_chunk_samples(void* v);      /* samples one decode of chunk_tokens frames returns (<= chunk_tokens * samples_per_token) */
 
 /* codes[B][chunk_tokens][16] int64 (ids 0..2047; out-of-range ids embed as zeros) ->
- * out[B][chunk_tokens*1920] f32 in [-1, 1].  0 ok / <0 error. */
+ * out[B][voc_chunk_samples()] f32 in [-1, 1] (the ONNX output tensor's shape).  0 ok / <0 error. */
 int voc_decode(void* v, const int64_t* codes, int B, float* out);
 
 /* VocoderServer.synthesize + int16 conversion for one utterance: codes[n][16] -> out samples.
- * out must hold voc_synthesize_max_samples(n) int16.  Returns 0 and *n_samples, or <0. */
+ * out must hold voc_synthesize_max_samples(n) int16.  Returns 0 and *n_samples, or <0.
+ * (n > chunk_tokens walks chunks with a 16-frame overlap: needs chunk_tokens > 32.) */
 int voc_synthesize(void* v, const int64_t* codes, int n_tokens, int16_t* out, int32_t* n_samples);
 /* same, float output before the int16 rule */
 int voc_synthesize_f32(void* v, const int64_t* codes, int n_tokens, float* out, int32_t* n_samples);

@@ -1,7 +1,11 @@
-"""Independent fp32 / float64 reference of the vocoder program (torch CPU ops) -- test infrastructure
+"""Independent fp32 / float64 evaluation of the vocoder program (torch CPU ops) -- test infrastructure
 (only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import it).
-Follows the op-table semantics documented in DESIGN.md "Vocoder program"; the decoder's layer
-list itself is not in the reference: parity with the real model is unpinned."""
+Follows the op-table semantics documented in DESIGN.md "Vocoder program".  The decoder's layer list is not in the
+reference (scripts/export_vocoder_traced.py:38-52 only drives `decoder(codes[B,16,T])`); what pins
+this file is the importable implementation of that decoder family: tests/test_code2wav_golden.py feeds it the
+state_dict() of transformers' Qwen3OmniMoeCode2Wav (+ Mimi's split RVQ) through weights.state_to_voc and requires the
+outputs stored by tests/golden/make_code2wav_golden.py to <= 1e-5.  Parity with the real Qwen3-TTS checkpoint stays
+unpinned (no weights, no qwen_tts here)."""
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -36,6 +40,13 @@ def voc_reference(tensors: dict, codes: np.ndarray, n_ops: int = -1, dtype=np.fl
                 sem, ac = emb[0], emb[1:].sum(0)
                 y = sem @ t(p + "proj_sem").T + ac @ t(p + "proj_ac").T
                 x = y.transpose(1, 2).contiguous()
+            elif op == W.VOP_EMBMEAN:   # code_embedding(codes + q * size).mean(q)   (Qwen3OmniMoeCode2Wav.forward)
+                nq, cbs = int(row[1]), int(row[2])
+                tab = t(p + "embedding")
+                valid = ((codes_t >= 0) & (codes_t < cbs)).to(tab.dtype)
+                idx = codes_t.clamp(0, cbs - 1) + torch.arange(nq)[None, None, :] * cbs
+                y = (tab[idx[..., :nq]] * valid[..., :nq, None]).mean(2)            # [B,T,dim]
+                x = y.transpose(1, 2).contiguous()
             elif op in (W.VOP_CONV, W.VOP_CONVT):
                 k, p0, flags = int(row[3]), int(row[4]), int(row[5])
                 if flags & W.VF_RES_SAVE:
@@ -47,7 +58,10 @@ def voc_reference(tensors: dict, codes: np.ndarray, n_ops: int = -1, dtype=np.fl
                 if op == W.VOP_CONV:
                     y = F.conv1d(F.pad(h, ((k - 1) * p0, 0)), t(p + "weight"), bias, dilation=p0)
                 else:
-                    y = F.conv_transpose1d(h, t(p + "weight"), bias, stride=p0)[..., : h.shape[-1] * p0]
+                    # (L - 1) * stride + k outputs, row[6] cut on the left, row[7] on the right
+                    # (Qwen3OmniMoeCausalTransConvNet: both = k - stride)
+                    y = F.conv_transpose1d(h, t(p + "weight"), bias, stride=p0)
+                    y = y[..., int(row[6]): y.shape[-1] - int(row[7])].contiguous()
                 if flags & W.VF_RES_ADD:
                     y = y + res
                 if flags & W.VF_CLAMP:

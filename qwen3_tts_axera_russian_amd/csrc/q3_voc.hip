@@ -23,7 +23,7 @@ namespace q3 {
 
 typedef float f16v __attribute__((ext_vector_type(16)));
 
-enum { VOP_RVQ = 1, VOP_CONV = 2, VOP_CONVT = 3, VOP_DWCONV = 4, VOP_NORM = 5, VOP_ATTN = 6, VOP_GLU = 7 };
+enum { VOP_RVQ = 1, VOP_CONV = 2, VOP_CONVT = 3, VOP_DWCONV = 4, VOP_NORM = 5, VOP_ATTN = 6, VOP_GLU = 7, VOP_EMBMEAN = 8 };
 enum { VF_SNAKE = 1, VF_RES_ADD = 2, VF_RES_SAVE = 4, VF_CLAMP = 8, VF_GELU = 16 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
@@ -39,6 +39,15 @@ struct ConvArgs {
     const float* res = nullptr;       // [B][Cout][L] added in the epilogue
     int gelu = 0;                     // exact GELU applied to the input (ConvNeXt's second pointwise conv)
     int Cin = 0, M = 0, K = 0, dil = 1, Lin = 0, stride = 1, Cout = 0, clamp = 0;
+    // Activations are [B][C][ld]: rows of L valid columns at a pitch ld = L rounded up to 4 floats, so that every row
+    // starts 16-byte aligned whatever L is (the transposed convs of the decoder family trim k - s samples at both ends:
+    // 64 frames -> 256 -> 2040 -> 10195 -> 40776 -> 122325 columns).  Pad columns hold junk that only ever feeds pad
+    // columns: every op is causal per column (a GEMM column depends on its own B column only).
+    int ldx = 0, ldy = 0;
+    // transposed conv: virtual row m = co * stride + p of input column l lands at output column l * stride + p - lt
+    // (lt samples trimmed on the left), kept when 0 <= that < Lout; Lc = columns of the polyphase GEMM that reach a
+    // kept output (= Lin for the trims in use; inputs at l >= Lin read as zero)
+    int lt = 0, Lout = 0, Lc = 0;
     int n_tiles = 0, tiles_l = 0, tiles_m = 0;  // set by the launcher
     // one-tap, stride-1 convs (pointwise projections): the columns of all B chunks form ONE axis of B*Lin columns
     // (a column needs no neighbour), so 128-column tiles stay full when a chunk is only 64 columns long
@@ -66,8 +75,8 @@ __global__ void __launch_bounds__(256, MT >= 4 ? 3 : (MT == 3 ? 3 : 4)) conv_ker
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int lx = tile % a.tiles_l, my = (tile / a.tiles_l) % a.tiles_m, b = tile / (a.tiles_l * a.tiles_m);
         const int l0 = lx * VTN, m0 = my * TM;
-        const float* xb = a.x + (size_t)b * a.Cin * a.Lin;
-        const int Lcols = a.flat_B > 0 ? a.flat_B * a.Lin : a.Lin;   // columns of the tiled axis
+        const float* xb = a.x + (size_t)b * a.Cin * a.ldx;
+        const int Lcols = a.flat_B > 0 ? a.flat_B * a.ldx : a.Lc;   // columns of the tiled axis (flattened: pads included)
         f16v acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
@@ -103,15 +112,15 @@ __global__ void __launch_bounds__(256, MT >= 4 ? 3 : (MT == 3 ? 3 : 4)) conv_ker
             for (int j = 0; j < (KT == 1 ? XJ1 : 1); j++) {
                 const int c4 = (xl + j * LPC) * 4, c4c = c4 < VTN ? c4 : 0;
                 const int gl = l0 + c4c, glc = gl < Lcols ? gl : 0;
-                const int bb = a.flat_B > 0 ? glc / a.Lin : 0, l = glc - bb * a.Lin;   // (4 | Lin: a group stays in its chunk)
-                xv1[j] = *(const float4*)(xb + (unsigned)((bb * a.Cin + ci0 + xci) * a.Lin + l));
+                const int bb = a.flat_B > 0 ? glc / a.ldx : 0, l = glc - bb * a.ldx;   // (4 | ldx: a group stays in its chunk)
+                xv1[j] = *(const float4*)(xb + (unsigned)((bb * a.Cin + ci0 + xci) * a.ldx + l));
             }
         };
         // One tap: the stage is short (KC / 2 MFMAs per row tile), so the NEXT stage's operands are requested into
         // registers before this stage's MFMAs and land under them (2 + 2 float4 per thread at 16 channels); with more
         // taps the prefetch registers cost a workgroup per CU (tried: 1.6x slower).
         // (32-channel stages keep the plain form: 16 + 16 more live registers put the 128-row tile 99 registers over)
-        const bool al1 = KT == 1 && (a.Lin & 3) == 0;      // one tap, aligned: 16-byte staging
+        const bool al1 = KT == 1;                           // one tap: 16-byte staging (rows are 16-byte aligned: 4 | ldx)
         const bool pre1 = al1 && KC <= 16;                  // ... with the next stage prefetched
         if (pre1) {
             load_w(0);
@@ -165,7 +174,7 @@ __global__ void __launch_bounds__(256, MT >= 4 ? 3 : (MT == 3 ? 3 : 4)) conv_ker
                     for (int j = 0; j < XB; j++) {
                         const int col = xl + (j0 + j) * LPC;
                         const int l = l0 - halo + col, lc = (col < XW && l >= 0 && l < a.Lin) ? l : 0;
-                        xv[j] = xb[(unsigned)((ci0 + xci) * a.Lin + lc)];
+                        xv[j] = xb[(unsigned)((ci0 + xci) * a.ldx + lc)];
                     }
                     if (j0 == 0) store_w();
 #pragma unroll
@@ -207,9 +216,8 @@ __global__ void __launch_bounds__(256, MT >= 4 ? 3 : (MT == 3 ? 3 : 4)) conv_ker
         }
         // epilogue.  D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
         const int gl = l0 + w * 32 + (lane & 31);
-        const int be = a.flat_B > 0 ? gl / a.Lin : b;
-        const int l = a.flat_B > 0 ? gl - be * a.Lin : gl;
-        const int Lout = a.Lin * a.stride;
+        const int be = a.flat_B > 0 ? gl / a.ldx : b;
+        const int l = a.flat_B > 0 ? gl - be * a.ldx : gl;
         if constexpr (CT) {
             // transposed conv: row m = co * stride + p lands at y[co][l * stride + p] -- stored straight from the D
             // layout that is one 4-byte store per lane at a stride of `stride` floats (32-byte sectors filled a few
@@ -227,16 +235,17 @@ __global__ void __launch_bounds__(256, MT >= 4 ? 3 : (MT == 3 ? 3 : 4)) conv_ker
                 __syncthreads();
                 const int m_lo = m0 + mt * 32, m_hi = (m_lo + 32 < a.M) ? m_lo + 32 : a.M;
                 if (m_lo < m_hi) {
-                    const int ncol = (a.Lin - l0 < VTN) ? a.Lin - l0 : VTN;   // live columns of this tile
+                    const int ncol = (a.Lc - l0 < VTN) ? a.Lc - l0 : VTN;   // live columns of this tile
                     for (int co = m_lo / s; co * s < m_hi; co++) {
                         const float bv = a.bias ? a.bias[co] : 0.f;
-                        float* yrow = a.y + (size_t)b * a.Cout * Lout + (unsigned)(co * Lout + l0 * s);
+                        float* yrow = a.y + (size_t)b * a.Cout * a.ldy + (unsigned)(co * a.ldy);
                         for (int j = tid; j < ncol * s; j += 256) {
                             const int lc = j / s, ph = j - lc * s, m = co * s + ph;
-                            if (m >= m_lo && m < m_hi) {
+                            const int jo = l0 * s + j - a.lt;                     // output column after the left trim
+                            if (m >= m_lo && m < m_hi && jo >= 0 && jo < a.Lout) {
                                 float v = T[(m - m_lo) * TP + lc] + bv;
                                 if (a.clamp) v = fminf(fmaxf(v, -1.f), 1.f);
-                                __builtin_nontemporal_store(v, &yrow[j]);
+                                __builtin_nontemporal_store(v, &yrow[jo]);
                             }
                         }
                     }
@@ -251,7 +260,9 @@ __global__ void __launch_bounds__(256, MT >= 4 ? 3 : (MT == 3 ? 3 : 4)) conv_ker
                     if (m < a.M) {
                         const int co = a.stride == 1 ? m : m / a.stride;
                         const int p = a.stride == 1 ? 0 : m % a.stride;
-                        const unsigned idx = (unsigned)((be * a.Cout + co) * Lout + l * a.stride + p);   // (launcher: < 2^31)
+                        const int jo = l * a.stride + p - a.lt;                    // (stride 1: lt = 0, every column is kept)
+                        if (a.stride != 1 && (jo < 0 || jo >= a.Lout)) continue;
+                        const unsigned idx = (unsigned)((be * a.Cout + co) * a.ldy + jo);   // (launcher: < 2^31)
                         float v = acc[mt][r];
                         if (a.bias) v += a.bias[co];
                         if (a.res) v += a.res[idx];
@@ -292,15 +303,18 @@ static int launch_conv_t(hipStream_t s, const ConvArgs& a, int B) {
     }
     ConvArgs c = a;
     c.Mp = (a.M + 3) / 4 * 4;
-    c.flat_B = (KT == 1 && a.stride == 1 && (a.Lin & 3) == 0) ? B : 0;
+    c.flat_B = (KT == 1 && a.stride == 1) ? B : 0;
+    if ((a.ldx & 3) || (a.ldy & 3) || a.ldx < a.Lin || a.ldy < a.Lout || a.Lc < a.Lin || a.Lc > a.Lin + KT - 1) {
+        Q3_LOG("voc conv: bad geometry (Lin %d pitch %d, Lout %d pitch %d, Lc %d)", a.Lin, a.ldx, a.Lout, a.ldy, a.Lc);
+        return -1;
+    }
     {   // the kernel indexes activations with 32-bit offsets from a.x / a.y (all chunks: the epilogue's `be` is per lane)
-        const size_t cmax = (size_t)(a.Cin > a.Cout ? a.Cin : a.Cout);
-        if ((size_t)B * cmax * a.Lin * a.stride >= ((size_t)1 << 31)) {
-            Q3_LOG("voc conv: activation of %d x %zu x %d floats is beyond the kernel's 32-bit indexing", B, cmax, a.Lin * a.stride);
+        if ((size_t)B * a.Cin * a.ldx >= ((size_t)1 << 31) || (size_t)B * a.Cout * a.ldy >= ((size_t)1 << 31)) {
+            Q3_LOG("voc conv: activation of %d x %d x %d / %d x %d x %d floats is beyond the kernel's 32-bit indexing", B, a.Cin, a.ldx, B, a.Cout, a.ldy);
             return -1;
         }
     }
-    c.tiles_l = ((c.flat_B > 0 ? a.Lin * B : a.Lin) + VTN - 1) / VTN;
+    c.tiles_l = ((c.flat_B > 0 ? a.ldx * B : a.Lc) + VTN - 1) / VTN;
     c.tiles_m = (a.M + TM - 1) / TM;
     c.n_tiles = c.tiles_l * c.tiles_m * (c.flat_B > 0 ? 1 : B);
     int grid = c.n_tiles;
@@ -321,8 +335,8 @@ static int launch_conv_mt(hipStream_t s, const ConvArgs& a, int B) {
     // covers the chip twice (measured, 32 chunks: pre-transformer 5.8 -> 4.2 ms, the 4096 -> 1024 ConvNeXt conv 0.83 -> 0.62)
     static const int fill = getenv("Q3_VOC_FILL") ? atoi(getenv("Q3_VOC_FILL")) : 512;
     if (fill > 0) {
-        const long cols = (KT == 1 && a.stride == 1 && (a.Lin & 3) == 0) ? (long)a.Lin * B : (long)a.Lin;
-        const long col_tiles = (cols + VTN - 1) / VTN * ((KT == 1 && a.stride == 1 && (a.Lin & 3) == 0) ? 1 : B);
+        const long cols = (KT == 1 && a.stride == 1) ? (long)a.ldx * B : (long)a.Lc;
+        const long col_tiles = (cols + VTN - 1) / VTN * ((KT == 1 && a.stride == 1) ? 1 : B);
         while (mt > 1 && col_tiles * ((t32 + mt - 1) / mt) < fill) mt = (mt == 4 || mt == 2) ? mt / 2 : 1;
     }
     switch (mt) {
@@ -344,13 +358,13 @@ __global__ void __launch_bounds__(256) conv_out1_kernel(ConvArgs a) {
     const int b = blockIdx.y;
     const int l0 = (blockIdx.x * 256 + threadIdx.x) * 8;
     if (l0 >= a.Lin) return;
-    const float* xb = a.x + (size_t)b * a.Cin * a.Lin;
+    const float* xb = a.x + (size_t)b * a.Cin * a.ldx;
     float acc[8];
     const float b0 = a.bias ? a.bias[0] : 0.f;
 #pragma unroll
     for (int j = 0; j < 8; j++) acc[j] = b0;
     for (int c = 0; c < a.Cin; c++) {
-        const float* xr = xb + (size_t)c * a.Lin;
+        const float* xr = xb + (size_t)c * a.ldx;      // (16-byte aligned: 4 | ldx)
         float v[16];   // columns l0 - 8 .. l0 + 7
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -381,7 +395,7 @@ __global__ void __launch_bounds__(256) conv_out1_kernel(ConvArgs a) {
             for (int j = 0; j < 8; j++) acc[j] = fmaf(wv, v[2 + j + k], acc[j]);   // tap k reads column l - (6 - k)
         }
     }
-    float* yb = a.y + (size_t)b * a.Lin;
+    float* yb = a.y + (size_t)b * a.ldy;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         float o = acc[j];
@@ -397,8 +411,8 @@ static int launch_conv(hipStream_t s, const ConvArgs& a, int B) {
         return -1;
     }
     static const int out1 = getenv("Q3_VOC_OUT1") ? atoi(getenv("Q3_VOC_OUT1")) : 1;
-    if (out1 && a.M == 1 && a.K == 7 && a.dil == 1 && a.stride == 1 && !a.res && !a.gelu && (a.Lin & 3) == 0 &&
-        (size_t)B * c * a.Lin < ((size_t)1 << 31)) {
+    if (out1 && a.M == 1 && a.K == 7 && a.dil == 1 && a.stride == 1 && !a.res && !a.gelu && (a.ldx & 3) == 0 &&
+        (size_t)B * c * a.ldx < ((size_t)1 << 31)) {
         ConvArgs k = a;
         k.Mp = 4;
         hipLaunchKernelGGL(conv_out1_kernel, dim3((a.Lin + 2047) / 2048, B), dim3(256), 0, s, k);
@@ -440,7 +454,7 @@ struct ResUnitArgs {
     const float *b7 = nullptr, *b1 = nullptr;                    // biases (may be null)
     const float *al7 = nullptr, *ib7 = nullptr;                  // Snake of the unit's input
     const float *al1 = nullptr, *ib1 = nullptr;                  // Snake between the convs
-    int Lin = 0, dil = 1, tiles_l = 0, n_tiles = 0;
+    int Lin = 0, ld = 0, dil = 1, tiles_l = 0, n_tiles = 0;   // ld: row pitch of x and y (ConvArgs)
 };
 
 static int g_voc_fuse = 1;   // 1 (default): residual units at <= 192 channels run fused on the exact path
@@ -463,7 +477,7 @@ __global__ void __launch_bounds__(256, MT <= 3 ? 3 : 2) resunit_kernel(ResUnitAr
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int lx = tile % a.tiles_l, b = tile / a.tiles_l;
         const int l0 = lx * VTN;
-        const float* xb = a.x + (size_t)b * C * a.Lin;
+        const float* xb = a.x + (size_t)b * C * a.ld;
         f16v acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
@@ -489,7 +503,7 @@ __global__ void __launch_bounds__(256, MT <= 3 ? 3 : 2) resunit_kernel(ResUnitAr
             for (int j = 0; j < XJ; j++) {
                 const int col = xl + j * LPC;
                 const int l = l0 - halo + col, lc = (col < XW && l >= 0 && l < a.Lin) ? l : 0;
-                xv[j] = xb[(unsigned)((ci0 + xci) * a.Lin + lc)];
+                xv[j] = xb[(unsigned)((ci0 + xci) * a.ld + lc)];
             }
 #pragma unroll
             for (int i = 0; i < WIT; i++) {
@@ -544,11 +558,11 @@ __global__ void __launch_bounds__(256, MT <= 3 ? 3 : 2) resunit_kernel(ResUnitAr
             // element (row m, column gl): the row splits into a wave-uniform part (32 mt2 + the register's row: scalar
             // address arithmetic) and ONE per-lane offset; written as 16 per-lane offsets the compiler computed all of
             // them (and the 16 of the stores) at kernel entry and spilled them (36 registers, round 2)
-            const unsigned lane_off = (unsigned)(4 * (lane >> 5) * a.Lin + (live ? gl : 0));
+            const unsigned lane_off = (unsigned)(4 * (lane >> 5) * a.ld + (live ? gl : 0));
             float res[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const float* rowp = xb + (unsigned)((32 * mt2 + (r & 3) + 8 * (r >> 2)) * a.Lin);
+                const float* rowp = xb + (unsigned)((32 * mt2 + (r & 3) + 8 * (r >> 2)) * a.ld);
                 res[r] = rowp[lane_off];
             }
             __syncthreads();   // the 7-tap stage (or the previous row tile) is consumed by every wave
@@ -567,11 +581,11 @@ __global__ void __launch_bounds__(256, MT <= 3 ? 3 : 2) resunit_kernel(ResUnitAr
                 for (int q = 0; q < 16; q++)
                     o = __builtin_amdgcn_mfma_f32_32x32x2f32(Ws[(mt * 16 + q) * 64 + lane], acc[mt][q], o, 0, 0, 0);
             if (live) {
-                float* yb = a.y + (size_t)b * C * a.Lin;
+                float* yb = a.y + (size_t)b * C * a.ld;
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int mu = 32 * mt2 + (r & 3) + 8 * (r >> 2);
-                    float* rowp = yb + (unsigned)(mu * a.Lin);
+                    float* rowp = yb + (unsigned)(mu * a.ld);
                     __builtin_nontemporal_store(o[r] + Ps[3 * C + mu + 4 * (lane >> 5)] + res[r], &rowp[lane_off]);
                 }
             }
@@ -619,14 +633,14 @@ typedef _Float16 hv8 __attribute__((ext_vector_type(8)));
 
 __global__ void __launch_bounds__(256) snake_split_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
                                                           const float* __restrict__ inv_beta, _Float16* __restrict__ xh,
-                                                          _Float16* __restrict__ xl, int C, int L, int gelu,
+                                                          _Float16* __restrict__ xl, int C, int L, int ld, int gelu,
                                                           int* __restrict__ ovf) {
     const int l = blockIdx.x * 256 + threadIdx.x, cg = blockIdx.y, b = blockIdx.z;   // cg: 8-channel group
     if (l >= L) return;
-    const float* xp = x + ((size_t)b * C + cg * 8) * L + l;
+    const float* xp = x + ((size_t)b * C + cg * 8) * ld + l;     // f32 rows at pitch ld; the planes are dense in L
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) v[j] = xp[(size_t)j * L];
+    for (int j = 0; j < 8; j++) v[j] = xp[(size_t)j * ld];
     if (alpha) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -669,6 +683,7 @@ struct SplitArgs {
     const float* oinv_beta = nullptr;
     int* ovf = nullptr;                  // set to 1 when an output plane value leaves the fp16 range
     int Cin = 0, M = 0, Mp = 0, dil = 1, Lin = 0, stride = 1, Cout = 0, clamp = 0, B = 0;
+    int ldy = 0, lt = 0, Lout = 0, Lc = 0;   // f32 output pitch, left trim / kept outputs / GEMM columns (ConvArgs)
     int n_tiles = 0, tiles_l = 0, tiles_m = 0;
     int my_fast = 0;   // tile order, see conv_split_kernel
 };
@@ -775,14 +790,13 @@ __global__ void __launch_bounds__(256, NJ == 1 ? 3 : 2) conv_split_kernel(SplitA
                     }
             }
         }
-        const int Lout = a.Lin * a.stride;
         typedef _Float16 hv4 __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int i = 0; i < MW; i++)
 #pragma unroll
             for (int j = 0; j < NJ; j++) {
                 const int l = l0 + w * (32 * NJ) + j * 32 + (lane & 31);
-                if (l < a.Lin) {
+                if (l < a.Lc) {
                     float rv[16];
 #pragma unroll
                     for (int r = 0; r < 16; r++) {     // the residual reads of the whole 32x32 tile go out together
@@ -791,7 +805,7 @@ __global__ void __launch_bounds__(256, NJ == 1 ? 3 : 2) conv_split_kernel(SplitA
                         if (a.res && m < a.M) {
                             const int co = a.stride == 1 ? m : m / a.stride;
                             const int p = a.stride == 1 ? 0 : m % a.stride;
-                            rv[r] = a.res[((size_t)b * a.Cout + co) * Lout + (size_t)l * a.stride + p];
+                            rv[r] = a.res[((size_t)b * a.Cout + co) * a.ldy + (size_t)l * a.stride + p];   // (stride 1 only)
                         }
                     }
 #pragma unroll
@@ -805,11 +819,12 @@ __global__ void __launch_bounds__(256, NJ == 1 ? 3 : 2) conv_split_kernel(SplitA
                             if (m < a.M) {
                                 const int co = a.stride == 1 ? m : m / a.stride;
                                 const int p = a.stride == 1 ? 0 : m % a.stride;
-                                const size_t idx = ((size_t)b * a.Cout + co) * Lout + (size_t)l * a.stride + p;
+                                const int jo = l * a.stride + p - a.lt;          // output column after the left trim
+                                const size_t idx = ((size_t)b * a.Cout + co) * a.ldy + (size_t)(jo > 0 ? jo : 0);
                                 if (a.bias) v[q] += a.bias[co];
                                 v[q] += rv[r];
                                 if (a.clamp) v[q] = fminf(fmaxf(v[q], -1.f), 1.f);
-                                if (a.y) a.y[idx] = v[q];
+                                if (a.y && jo >= 0 && jo < a.Lout) a.y[idx] = v[q];
                             }
                         }
                         if (a.oh && mg < a.M) {
@@ -852,7 +867,7 @@ static int launch_conv_split_t(hipStream_t s, const SplitArgs& a, int B) {
     if (lds > 80 * 1024 || (a.Cin / 16) % KS || a.Mp % STM) return -1;   // <= 80 KB: two workgroups per CU
     SplitArgs c = a;
     c.B = B;
-    c.tiles_l = (a.Lin + STN - 1) / STN;
+    c.tiles_l = (a.Lc + STN - 1) / STN;
     c.tiles_m = (a.M + STM - 1) / STM;
     c.n_tiles = c.tiles_l * c.tiles_m * B;
     // both planes of all taps of the weights: small enough to live in every XCD's 4 MiB L2 beside the stream?
@@ -890,7 +905,7 @@ static int launch_conv_split_m(hipStream_t s, const SplitArgs& a, int K, int B) 
 static int launch_conv_split(hipStream_t s, const SplitArgs& a, int K, int B) {
     // 96-row tiles where they tile the rows exactly (every channel count of the decoder blocks) and still
     // give the chip enough workgroups: the input tile is read by Cout/96 workgroups instead of Cout/64
-    const long tiles96 = (long)((a.Lin + 255) / 256) * (a.M / 96) * B;
+    const long tiles96 = (long)((a.Lc + 255) / 256) * (a.M / 96) * B;
     const bool fits96 = a.M % 96 == 0 && a.Mp % 96 == 0;
     const bool use96 = fits96 && (a.Mp % 64 != 0 || tiles96 >= 512);
     return use96 ? launch_conv_split_m<3>(s, a, K, B) : launch_conv_split_m<2>(s, a, K, B);
@@ -902,16 +917,16 @@ static int launch_conv_split(hipStream_t s, const SplitArgs& a, int K, int B) {
 // ---------------------------------------------------------------------------
 // causal depthwise conv: y[c][l] = bias[c] + sum_k w[c][k] * x[c][l - (K-1-k)]
 __global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                     const float* __restrict__ bias, float* __restrict__ y, int C, int L, int K) {
+                                                     const float* __restrict__ bias, float* __restrict__ y, int C, int L, int ld, int K) {
     const int l = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
     if (l >= L) return;
-    const float* xr = x + ((size_t)b * C + c) * L;
+    const float* xr = x + ((size_t)b * C + c) * ld;
     float acc = bias ? bias[c] : 0.f;
     for (int k = 0; k < K; k++) {
         const int ls = l - (K - 1 - k);
         if (ls >= 0) acc += w[c * K + k] * xr[ls];
     }
-    y[((size_t)b * C + c) * L + l] = acc;
+    y[((size_t)b * C + c) * ld + l] = acc;
 }
 
 // RMSNorm (kind 0) / LayerNorm (kind 1) over the channels of every column.  Workgroup = 64 columns x 16 channel
@@ -919,12 +934,12 @@ __global__ void __launch_bounds__(256) dwconv_kernel(const float* __restrict__ x
 // Two-pass variance (mean first), like the reference implementation.
 __global__ void __launch_bounds__(1024) chan_norm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y, int C, int L,
-                                                         int kind, float eps) {
+                                                         int ld, int kind, float eps) {
     __shared__ float part[16][64];
     const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int l = blockIdx.x * 64 + col, b = blockIdx.y;
     const bool ok = l < L;
-    const float* xc = x + (size_t)b * C * L + (ok ? l : 0);
+    const float* xc = x + (size_t)b * C * ld + (ok ? l : 0);
     auto column_sum = [&](float v) -> float {     // sum over the 16 channel lanes of a column, identical in all of them
         part[g][col] = v;
         __syncthreads();
@@ -937,28 +952,29 @@ __global__ void __launch_bounds__(1024) chan_norm_kernel(const float* __restrict
     float mu = 0.f;
     if (kind == 1) {
         float s_ = 0.f;
-        for (int c = g; c < C; c += 16) s_ += xc[(size_t)c * L];
+        for (int c = g; c < C; c += 16) s_ += xc[(size_t)c * ld];
         mu = column_sum(s_) / (float)C;
     }
     float ss = 0.f;
     for (int c = g; c < C; c += 16) {
-        const float d = xc[(size_t)c * L] - mu;
+        const float d = xc[(size_t)c * ld] - mu;
         ss += d * d;
     }
     const float inv = 1.0f / sqrtf(column_sum(ss) / (float)C + eps);
     if (!ok) return;
-    float* yc = y + (size_t)b * C * L + l;
+    float* yc = y + (size_t)b * C * ld + l;
     for (int c = g; c < C; c += 16) {
-        float v = (xc[(size_t)c * L] - mu) * inv * w[c];
+        float v = (xc[(size_t)c * ld] - mu) * inv * w[c];
         if (bias) v += bias[c];
-        yc[(size_t)c * L] = v;
+        yc[(size_t)c * ld] = v;
     }
 }
 
 // x = [q | k | v] (head-major channels, [3*H*D][L]) -> causal sliding-window attention with rotate-half RoPE
 // (positions = columns of the chunk).  One wave per (query column, head); lane j owns the pair (j, j + D/2).
-__global__ void __launch_bounds__(64) voc_attn_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int D, int L,
-                                                      int window, float theta) {
+__global__ void __launch_bounds__(64) voc_attn_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int D, int Lv,
+                                                      int L, int window, float theta) {
+    // L: row pitch (every row index below is scaled by it); Lv valid columns = the grid's x extent
     const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z, j = threadIdx.x;
     const int half = D / 2, HD = H * D;
     const bool on = j < half;
@@ -1010,12 +1026,12 @@ __global__ void __launch_bounds__(64) voc_attn_kernel(const float* __restrict__ 
 // chunks of the pre-transformer): one workgroup per (head, chunk) applies RoPE once per element while staging, then
 // every query is owned by 4 threads that split its keys 4 ways (online softmax each, merged by shuffles).
 __global__ void __launch_bounds__(256) voc_attn_tile_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int D,
-                                                            int L, int window, float theta) {
+                                                            int L, int ld, int window, float theta) {
     extern __shared__ float sm[];            // q[L][D+1] | k[L][D+1] | v[L][D+1]  (+1: conflict-free row walks)
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int half = D / 2, HD = H * D, DP = D + 1;
     float *qs = sm, *ks = sm + (size_t)L * DP, *vs = sm + (size_t)2 * L * DP;
-    const float* xb = x + (size_t)b * 3 * HD * L;
+    const float* xb = x + (size_t)b * 3 * HD * ld;
     // stage: element (d, l) of q / k rotated with its partner (d +- half, l); consecutive threads = consecutive l
     for (int idx = tid; idx < half * L; idx += 256) {
         const int j = idx / L, l = idx - j * L;
@@ -1023,8 +1039,8 @@ __global__ void __launch_bounds__(256) voc_attn_tile_kernel(const float* __restr
         __sincosf((float)l * __powf(theta, -2.0f * (float)j / (float)D), &sn, &cs);
 #pragma unroll
         for (int which = 0; which < 2; which++) {
-            const float* base = xb + (size_t)(which * HD + h * D) * L;
-            const float x0 = base[(size_t)j * L + l], x1 = base[(size_t)(j + half) * L + l];
+            const float* base = xb + (size_t)(which * HD + h * D) * ld;
+            const float x0 = base[(size_t)j * ld + l], x1 = base[(size_t)(j + half) * ld + l];
             float* dst = which == 0 ? qs : ks;
             dst[l * DP + j] = x0 * cs - x1 * sn;
             dst[l * DP + j + half] = x1 * cs + x0 * sn;
@@ -1032,7 +1048,7 @@ __global__ void __launch_bounds__(256) voc_attn_tile_kernel(const float* __restr
     }
     for (int idx = tid; idx < D * L; idx += 256) {
         const int d = idx / L, l = idx - d * L;
-        vs[l * DP + d] = xb[(size_t)(2 * HD + h * D + d) * L + l];
+        vs[l * DP + d] = xb[(size_t)(2 * HD + h * D + d) * ld + l];
     }
     __syncthreads();
     const float scale = 1.0f / sqrtf((float)D);
@@ -1071,23 +1087,23 @@ __global__ void __launch_bounds__(256) voc_attn_tile_kernel(const float* __restr
             m = mn;
         }
         if (i < L) {
-            float* yb = y + ((size_t)b * HD + h * D) * L + i;
+            float* yb = y + ((size_t)b * HD + h * D) * ld + i;
             // (static register indices: `o[d]` with d starting at the lane's kl put the 64 accumulators in scratch --
             // 272 B per thread, 0.3 GB of scratch writes per launch by PMC)
             const float inv = 1.0f / lsum;
 #pragma unroll
             for (int d = 0; d < 64; d++)
-                if (d < D && (d & 3) == kl) yb[(size_t)d * L] = o[d] * inv;
+                if (d < D && (d & 3) == kl) yb[(size_t)d * ld] = o[d] * inv;
         }
     }
 }
 
 // y[c][l] = act(x[c][l]) * x[C + c][l]; act 0 SiLU, 1 GELU
-__global__ void __launch_bounds__(256) glu_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int L, int act) {
+__global__ void __launch_bounds__(256) glu_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int L, int ld, int act) {
     const int l = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
     if (l >= L) return;
-    const float g = x[((size_t)b * 2 * C + c) * L + l], u = x[((size_t)b * 2 * C + C + c) * L + l];
-    y[((size_t)b * C + c) * L + l] = (act == 0 ? g / (1.0f + __expf(-g)) : gelu_erf(g)) * u;
+    const float g = x[((size_t)b * 2 * C + c) * ld + l], u = x[((size_t)b * 2 * C + C + c) * ld + l];
+    y[((size_t)b * C + c) * ld + l] = (act == 0 ? g / (1.0f + __expf(-g)) : gelu_erf(g)) * u;
 }
 
 // Split residual VQ de-quantisation: codes i64 [B][T][NQ] -> y [B][OUT][T].
@@ -1095,10 +1111,10 @@ __global__ void __launch_bounds__(256) glu_kernel(const float* __restrict__ x, f
 // through their own DIM->OUT projection (1x1 conv without bias); the two results add.
 __global__ void __launch_bounds__(256) rvq_kernel(const int64_t* __restrict__ codes, const float* __restrict__ cb,
                                                   const float* __restrict__ p_sem, const float* __restrict__ p_ac,
-                                                  float* __restrict__ y, int T, int NQ, int CB, int DIM, int OUT) {
+                                                  float* __restrict__ y, int T, int ld, int NQ, int CB, int DIM, int OUT) {
     extern __shared__ float e[];  // [2][DIM]
     const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int64_t* c = codes + ((size_t)b * T + t) * NQ;
+    const int64_t* c = codes + ((size_t)b * T + t) * 16;   // 16 ids per frame in a request (vocoder_server.py:78), the first NQ are used
     for (int d = tid; d < DIM; d += blockDim.x) {
         float s0 = 0.f, s1 = 0.f;
         const int64_t c0 = c[0];
@@ -1115,7 +1131,23 @@ __global__ void __launch_bounds__(256) rvq_kernel(const int64_t* __restrict__ co
         float acc = 0.f;
         for (int d = 0; d < DIM; d++) acc += p_sem[(size_t)o * DIM + d] * e[d];
         for (int d = 0; d < DIM; d++) acc += p_ac[(size_t)o * DIM + d] * e[DIM + d];
-        y[((size_t)b * OUT + o) * T + t] = acc;
+        y[((size_t)b * OUT + o) * ld + t] = acc;
+    }
+}
+
+// The embedding-mean front of the decoder family's Omni form (Qwen3OmniMoeCode2Wav.forward):
+// y[b][c][t] = mean_q table[q * CB + codes[b][t][q]][c]; an id outside [0, CB) contributes zero.
+__global__ void __launch_bounds__(256) embmean_kernel(const int64_t* __restrict__ codes, const float* __restrict__ tab,
+                                                      float* __restrict__ y, int T, int ld, int NQ, int NQS, int CB, int DIM) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    const int64_t* c = codes + ((size_t)b * T + t) * NQS;    // NQS ids per frame in the request, the first NQ are used
+    for (int d = threadIdx.x; d < DIM; d += blockDim.x) {
+        float s_ = 0.f;
+        for (int q = 0; q < NQ; q++) {
+            const int64_t cq = c[q];
+            if (cq >= 0 && cq < CB) s_ += tab[((size_t)q * CB + cq) * DIM + d];
+        }
+        y[((size_t)b * DIM + d) * ld + t] = s_ / (float)NQ;
     }
 }
 
@@ -1128,10 +1160,21 @@ struct VocOp {
     int Mp128 = 0;
     float *p_sem = nullptr, *p_ac = nullptr;
     float* w1p = nullptr;   // 1x1 conv closing a residual unit: A operands in resunit_kernel's K order
+    int lt = 0, rt = 0;     // transposed conv: samples trimmed from the (L - 1) * stride + k outputs, left / right
 };
+
+static inline long pitch4(long L) { return (L + 3) & ~3L; }
+// kept outputs of a transposed conv over L input columns
+static inline long convt_out(const VocOp& op, long L) { return (L - 1) * op.p0 + op.k - op.lt - op.rt; }
+// columns of its polyphase GEMM that reach a kept output (virtual row p of column l lands at l * s + p - lt)
+static inline long convt_cols(const VocOp& op, long L) {
+    const long lc = (convt_out(op, L) + op.lt + op.p0 - 1) / op.p0;
+    return lc < L ? L : lc;
+}
 
 struct Voc {
     int chunk = 64, max_batch = 1, upsample = 1;
+    long chunk_samples = 0;   // what one decode of `chunk` frames yields (<= chunk * upsample: the transposed convs trim)
     std::vector<VocOp> ops;
     std::vector<void*> allocs;
     hipStream_t s = nullptr;
@@ -1211,12 +1254,7 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
         Q3_LOG("%s holds no vocoder program (tensor voc.program int32 [n][8])", weights);
         return nullptr;
     }
-    if (chunk_tokens > 0 && chunk_tokens <= 32) {
-        // the chunk walk steps by chunk - 16 and its output bound (n + chunk) frames needs chunk > 32; the
-        // reference's models are traced at 64 or 256 (scripts/export_vocoder_traced.py)
-        Q3_LOG("voc_load: chunk_tokens=%d is too short for the 16-frame overlap walk (need > 32)", chunk_tokens);
-        return nullptr;
-    }
+    // (any chunk length decodes; the chunk walk of voc_synthesize needs chunk > 32 and says so itself)
     if (const char* ex = getenv("Q3_VOC_EXACT")) g_voc_split = atoi(ex) ? 0 : 1;
     Voc* v = new Voc();
     v->chunk = chunk_tokens > 0 ? chunk_tokens : 64;
@@ -1258,13 +1296,32 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
             }
             return t;
         };
-        if (op.op == VOP_RVQ) {
+        if (op.op == VOP_EMBMEAN) {
+            op.nq = r[1];
+            op.cb = r[2];
+            op.cout = r[3];  // embedding width
+            const PackTensor* tb = need("embedding");
+            if (!ok) break;
+            if (op.nq < 1 || op.nq > 16 || tb->numel() != (uint64_t)op.nq * op.cb * op.cout) {
+                Q3_LOG("vocoder op %d: embedding table size does not match the program (1..16 quantisers)", i);
+                ok = false;
+                break;
+            }
+            op.w = voc_up(v, tb);
+            ok = op.w != nullptr;
+            C = op.cout;
+        } else if (op.op == VOP_RVQ) {
             op.nq = r[1];
             op.cb = r[2];
             op.cin = r[3];   // codebook dim
             op.cout = r[4];  // output channels
             const PackTensor *cb = need("codebook"), *ps = need("proj_sem"), *pa = need("proj_ac");
             if (!ok) break;
+            if (op.nq < 1 || op.nq > 16) {
+                Q3_LOG("vocoder op %d: %d quantisers (a request carries 16 ids per frame)", i, op.nq);
+                ok = false;
+                break;
+            }
             if (cb->numel() != (uint64_t)op.nq * op.cb * op.cin || ps->numel() != (uint64_t)op.cout * op.cin ||
                 pa->numel() != (uint64_t)op.cout * op.cin) {
                 Q3_LOG("vocoder op %d: RVQ tensor sizes do not match the program", i);
@@ -1283,6 +1340,16 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
             op.k = r[3];
             op.p0 = r[4];  // dilation (conv) or stride (convT)
             op.flags = r[5];
+            if (op.op == VOP_CONVT) {
+                op.lt = r[6];
+                op.rt = r[7];
+                // every kept output must come from the polyphase GEMM over the input's own columns (+ k/s - 1 more)
+                if (op.lt < 0 || op.rt < 0 || op.p0 <= 0 || op.lt + op.rt > op.k || convt_out(op, L) <= 0) {
+                    Q3_LOG("vocoder op %d: transposed conv k=%d s=%d cannot be trimmed by %d + %d", i, op.k, op.p0, op.lt, op.rt);
+                    ok = false;
+                    break;
+                }
+            }
             if (op.cin != C) {
                 Q3_LOG("vocoder op %d: expects %d input channels, previous op produced %d", i, op.cin, C);
                 ok = false;
@@ -1305,8 +1372,9 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
                         for (int k = 0; k < op.k; k++)
                             wk[((size_t)k * op.cout + co) * op.cin + ci] = src[((size_t)co * op.cin + ci) * op.k + k];
             } else {  // torch ConvTranspose1d weight [cin][cout][k], k = J*stride: polyphase rows m = co*s + p,
-                      // tap j (input offset -j) reads w[ci][co][p + j*s]; conv tap index kk = J-1-j.  Causal:
-                      // the first Lin*s outputs are kept (the k-s trailing ones are trimmed).
+                      // tap j (input offset -j) reads w[ci][co][p + j*s]; conv tap index kk = J-1-j.  Row m of input
+                      // column l is output sample l*s + p of the untrimmed result; op.lt / op.rt samples are cut
+                      // at the ends (both k - s in the decoder family's CausalTransConvNet; 0 / k - s = strictly causal).
                 const int s = op.p0;
                 const int J = s > 0 ? op.k / s : 0;
                 if (s <= 0 || J < 1 || op.k != J * s) {
@@ -1408,7 +1476,7 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
             ok = ok && op.w;
             flops += 2.0 * op.cin * op.cout * op.k * L;  // per input column; convT: k taps spread over s outputs
             C = op.cout;
-            if (op.op == VOP_CONVT) L *= op.p0;
+            if (op.op == VOP_CONVT) L = convt_out(op, L);
         } else if (op.op == VOP_DWCONV || op.op == VOP_NORM || op.op == VOP_ATTN || op.op == VOP_GLU) {
             op.cin = r[1];
             op.cout = r[2];
@@ -1467,24 +1535,37 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
                 break;
             }
             C = op.cout;
-            if ((size_t)op.cin * L > max_elems) max_elems = (size_t)op.cin * L;
+            if ((size_t)op.cin * pitch4(L) > max_elems) max_elems = (size_t)op.cin * pitch4(L);
         } else {
             Q3_LOG("vocoder program op %d: unknown opcode %d", i, op.op);
             ok = false;
             break;
         }
-        if ((size_t)C * L > max_elems) max_elems = (size_t)C * L;
+        if ((size_t)C * pitch4(L) > max_elems) max_elems = (size_t)C * pitch4(L);
         v->ops.push_back(op);
     }
-    if (ok && (C != 1 || L % v->chunk != 0)) {
+    if (ok && C != 1) {
         Q3_LOG("vocoder program must end with 1 channel (got %d)", C);
         ok = false;
     }
     if (ok) {
-        v->upsample = (int)(L / v->chunk);
+        // nominal samples per frame = the product of the strides (decoder.total_upsample,
+        // scripts/export_vocoder_traced.py:46: what the callers' SAMPLES_PER_TOKEN is); a decode returns chunk_samples
+        long up = 1;
+        for (const VocOp& o : v->ops)
+            if (o.op == VOP_CONVT) up *= o.p0;
+        v->upsample = (int)up;
+        v->chunk_samples = L;
+        if (L > (long)v->chunk * up) {
+            Q3_LOG("vocoder program yields %ld samples for %d frames, more than %ld per frame", L, v->chunk, up);
+            ok = false;
+        }
+    }
+    if (ok) {
         v->flops_per_chunk = flops;
         v->buf_elems = max_elems * v->max_batch;
-        for (int i = 0; i < 3 && ok; i++) ok = hipMalloc((void**)&v->buf[i], v->buf_elems * 4) == hipSuccess;
+        for (int i = 0; i < 3 && ok; i++)     // (zeroed once: pad columns start finite)
+            ok = hipMalloc((void**)&v->buf[i], v->buf_elems * 4) == hipSuccess && hipMemset(v->buf[i], 0, v->buf_elems * 4) == hipSuccess;
         for (int i = 0; i < 4 && ok; i++) ok = hipMalloc((void**)&v->plane[i], v->buf_elems * 2) == hipSuccess;
         ok = ok && hipMalloc((void**)&v->d_codes, sizeof(int64_t) * 16 * v->chunk * v->max_batch) == hipSuccess;
         ok = ok && hipMalloc((void**)&v->d_ovf, 16) == hipSuccess && hipMemset(v->d_ovf, 0, 16) == hipSuccess;
@@ -1494,7 +1575,7 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
         voc_destroy(v);
         return nullptr;
     }
-    v->h_chunk.resize((size_t)v->chunk * v->upsample);
+    v->h_chunk.resize((size_t)v->chunk_samples);
     return v;
 }
 
@@ -1521,6 +1602,7 @@ int voc_set_max_workgroups(int n) {
 
 int voc_chunk_tokens(void* vv) { return vv ? ((Voc*)vv)->chunk : 0; }
 int voc_samples_per_token(void* vv) { return vv ? ((Voc*)vv)->upsample : 0; }
+int voc_chunk_samples(void* vv) { return vv ? (int)((Voc*)vv)->chunk_samples : 0; }
 float voc_last_decode_ms(void* vv) { return vv ? ((Voc*)vv)->last_ms : -1.f; }
 double voc_decode_flops(void* vv, int B) { return vv ? ((Voc*)vv)->flops_per_chunk * B : 0.0; }
 
@@ -1543,7 +1625,7 @@ static int voc_conv_split(Voc* v, const VocOp& op, const VocOp* next, bool last,
         if (!st.f32_cur) return -1;
         in_set = 0;
         hipLaunchKernelGGL(snake_split_kernel, dim3((unsigned)((L + 255) / 256), op.cin / 8, B), dim3(256), 0, v->s,
-                           v->buf[st.f32_idx], op.alpha, op.inv_beta, v->plane[0], v->plane[1], op.cin, (int)L,
+                           v->buf[st.f32_idx], op.alpha, op.inv_beta, v->plane[0], v->plane[1], op.cin, (int)L, (int)pitch4(L),
                            (op.flags & VF_GELU) ? 1 : 0, v->d_ovf);
         Q3_HIP(hipGetLastError(), -1);
     }
@@ -1571,11 +1653,16 @@ static int voc_conv_split(Voc* v, const VocOp& op, const VocOp* next, bool last,
         sa.dil = op.p0;
         sa.stride = 1;
         sa.M = op.cout;
+        sa.Lout = sa.Lc = (int)L;
     } else {
         sa.dil = 1;
         sa.stride = op.p0;
         sa.M = op.cout * op.p0;
+        sa.lt = op.lt;
+        sa.Lout = (int)convt_out(op, L);
+        sa.Lc = (int)convt_cols(op, L);
     }
+    sa.ldy = (int)pitch4(sa.Lout);
     int out_f32 = st.f32_idx;
     if (want_f32) {
         // never the buffer the residual (or a still-current f32 input) lives in
@@ -1616,9 +1703,14 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
         if (op_ms) hipEventRecord(v->e0, v->s);
         float* in = v->buf[cur];
         float* out = v->buf[cur ^ 1];
-        if (op.op == VOP_RVQ) {
-            hipLaunchKernelGGL(rvq_kernel, dim3(v->chunk, B), dim3(256), 2 * op.cin * sizeof(float), v->s, v->d_codes, op.w,
-                               op.p_sem, op.p_ac, out, v->chunk, op.nq, op.cb, op.cin, op.cout);
+        const int ld = (int)pitch4(L);
+        if (op.op == VOP_RVQ || op.op == VOP_EMBMEAN) {
+            if (op.op == VOP_RVQ)
+                hipLaunchKernelGGL(rvq_kernel, dim3(v->chunk, B), dim3(256), 2 * op.cin * sizeof(float), v->s, v->d_codes, op.w,
+                                   op.p_sem, op.p_ac, out, v->chunk, ld, op.nq, op.cb, op.cin, op.cout);
+            else
+                hipLaunchKernelGGL(embmean_kernel, dim3(v->chunk, B), dim3(256), 0, v->s, v->d_codes, op.w, out, v->chunk, ld,
+                                   op.nq, 16, op.cb, op.cout);
             Q3_HIP(hipGetLastError(), -1);
             C = op.cout;
             cur ^= 1;
@@ -1638,10 +1730,10 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
             }
             const unsigned lb = (unsigned)((L + 255) / 256);
             if (op.op == VOP_DWCONV)
-                hipLaunchKernelGGL(dwconv_kernel, dim3(lb, op.cin, B), dim3(256), 0, v->s, in, op.w, op.bias, out, op.cin, (int)L, op.k);
+                hipLaunchKernelGGL(dwconv_kernel, dim3(lb, op.cin, B), dim3(256), 0, v->s, in, op.w, op.bias, out, op.cin, (int)L, ld, op.k);
             else if (op.op == VOP_NORM)
                 hipLaunchKernelGGL(chan_norm_kernel, dim3((unsigned)((L + 63) / 64), B), dim3(1024), 0, v->s, in, op.w, op.bias, out, op.cin, (int)L,
-                                   op.kind, op.eps);
+                                   ld, op.kind, op.eps);
             else if (op.op == VOP_ATTN) {
                 const size_t tile_lds = (size_t)3 * L * (op.head_dim + 1) * sizeof(float);
                 if (op.head_dim <= 64 && op.head_dim % 2 == 0 && tile_lds <= 64 * 1024) {
@@ -1652,14 +1744,14 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
                         attr = true;
                     }
                     hipLaunchKernelGGL(voc_attn_tile_kernel, dim3(op.heads, B), dim3(256), tile_lds, v->s, in, out, op.heads,
-                                       op.head_dim, (int)L, op.window, op.theta);
+                                       op.head_dim, (int)L, ld, op.window, op.theta);
                 } else {
                     hipLaunchKernelGGL(voc_attn_kernel, dim3((unsigned)L, op.heads, B), dim3(64), 0, v->s, in, out, op.heads,
-                                       op.head_dim, (int)L, op.window, op.theta);
+                                       op.head_dim, (int)L, ld, op.window, op.theta);
                 }
             }
             else
-                hipLaunchKernelGGL(glu_kernel, dim3(lb, op.cout, B), dim3(256), 0, v->s, in, out, op.cout, (int)L, op.kind);
+                hipLaunchKernelGGL(glu_kernel, dim3(lb, op.cout, B), dim3(256), 0, v->s, in, out, op.cout, (int)L, ld, op.kind);
             Q3_HIP(hipGetLastError(), -1);
             C = op.cout;
             cur ^= 1;
@@ -1675,7 +1767,7 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
             }
             cur = st.f32_idx;
             C = op.cout;
-            if (op.op == VOP_CONVT) L *= op.p0;
+            if (op.op == VOP_CONVT) L = convt_out(op, L);
         } else if (g_voc_fuse && op.op == VOP_CONV && op.k == 7 && (op.flags & VF_RES_SAVE) && (op.flags & VF_SNAKE) &&
                    op.cin == op.cout && resunit_channels(op.cin) && i + 1 < nrun && v->ops[i + 1].w1p && st.f32_cur) {
             // a whole residual unit (this 7-tap conv + the 1x1 conv that closes it) in one launch
@@ -1693,6 +1785,7 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
             ra.al1 = op1.alpha;
             ra.ib1 = op1.inv_beta;
             ra.Lin = (int)L;
+            ra.ld = ld;
             ra.dil = op.p0;
             if (launch_resunit(v->s, ra, op.cin, B)) return -1;
             cur ^= 1;
@@ -1724,17 +1817,23 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
             a.Lin = (int)L;
             a.clamp = (op.flags & VF_CLAMP) ? 1 : 0;
             a.gelu = (op.flags & VF_GELU) ? 1 : 0;
+            a.ldx = ld;
             if (op.op == VOP_CONV) {
                 a.K = op.k;
                 a.dil = op.p0;
                 a.stride = 1;
                 a.M = op.cout;
+                a.Lout = a.Lc = (int)L;
             } else {
                 a.K = op.k / op.p0;
                 a.dil = 1;
                 a.stride = op.p0;
                 a.M = op.cout * op.p0;
+                a.lt = op.lt;
+                a.Lout = (int)convt_out(op, L);
+                a.Lc = (int)convt_cols(op, L);
             }
+            a.ldy = (int)pitch4(a.Lout);
             if (op.flags & VF_RES_SAVE) {
                 // the unit's input is needed again after two convs: it becomes buf[2] (pointer swap), out of the ping-pong
                 std::swap(v->buf[2], v->buf[cur]);
@@ -1744,7 +1843,7 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
             if (op.flags & VF_RES_ADD) a.res = res ? res : st.res;
             if (launch_conv(v->s, a, B)) return -1;
             C = op.cout;
-            if (op.op == VOP_CONVT) L *= op.p0;
+            if (op.op == VOP_CONVT) L = convt_out(op, L);
             cur ^= 1;
             st.f32_idx = cur;
             st.f32_cur = true;
@@ -1773,7 +1872,9 @@ int voc_decode(void* vv, const int64_t* codes, int B, float* out) {
     Q3_HIP(hipEventRecord(v->e1, v->s), -1);
     int ovf = 0;
     if (g_voc_split) Q3_HIP(hipMemcpyAsync(&ovf, v->d_ovf, sizeof(int), hipMemcpyDeviceToHost, v->s), -1);
-    Q3_HIP(hipMemcpyAsync(out, res, sizeof(float) * (size_t)B * v->chunk * v->upsample, hipMemcpyDeviceToHost, v->s), -1);
+    // rows of chunk_samples floats at the device pitch -> dense out[B][chunk_samples]
+    const size_t row = sizeof(float) * (size_t)v->chunk_samples, dpitch = sizeof(float) * (size_t)pitch4(v->chunk_samples);
+    Q3_HIP(hipMemcpy2DAsync(out, row, res, dpitch, row, (size_t)B, hipMemcpyDeviceToHost, v->s), -1);
     Q3_HIP(hipStreamSynchronize(v->s), -1);
     if (ovf) {
         // an activation beyond +-65504 (or a NaN): two fp16 terms cannot carry it -- this call is redone on the
@@ -1784,7 +1885,7 @@ int voc_decode(void* vv, const int64_t* codes, int B, float* out) {
         Q3_HIP(hipEventRecord(v->e0, v->s), -1);
         if (voc_run(v, B, &res, -1, nullptr, nullptr, nullptr, true)) return -1;
         Q3_HIP(hipEventRecord(v->e1, v->s), -1);
-        Q3_HIP(hipMemcpyAsync(out, res, sizeof(float) * (size_t)B * v->chunk * v->upsample, hipMemcpyDeviceToHost, v->s), -1);
+        Q3_HIP(hipMemcpy2DAsync(out, row, res, dpitch, row, (size_t)B, hipMemcpyDeviceToHost, v->s), -1);
         Q3_HIP(hipStreamSynchronize(v->s), -1);
     }
     hipEventElapsedTime(&v->last_ms, v->e0, v->e1);
@@ -1809,7 +1910,8 @@ int voc_debug_run(void* vv, const int64_t* codes, int B, int n_ops, float* out, 
     long LL = 0;
     if (voc_run(v, B, &res, n_ops, C, &LL)) return -1;
     *L = (int)LL;
-    Q3_HIP(hipMemcpyAsync(out, res, sizeof(float) * (size_t)B * (*C) * LL, hipMemcpyDeviceToHost, v->s), -1);
+    Q3_HIP(hipMemcpy2DAsync(out, sizeof(float) * (size_t)LL, res, sizeof(float) * (size_t)pitch4(LL), sizeof(float) * (size_t)LL,
+                            (size_t)B * (*C), hipMemcpyDeviceToHost, v->s), -1);
     Q3_HIP(hipStreamSynchronize(v->s), -1);
     return 0;
 }
@@ -1825,6 +1927,17 @@ int voc_synthesize_f32(void* vv, const int64_t* codes, int n, float* out, int32_
     Voc* v = (Voc*)vv;
     if (!v || !codes || !out || !n_samples || n <= 0) return -1;
     const int CH = v->chunk, SPT = v->upsample;
+    // numpy slicing, as the reference writes it: `audio[:len * SAMPLES_PER_TOKEN]` of what the model returned --
+    // a decode yields chunk_samples <= CH * SPT samples (the decoder family's transposed convs trim), so a slice is
+    // min(len * SPT, chunk_samples) long (vocoder_server.py:81,98-99)
+    const size_t CS = (size_t)v->chunk_samples;
+    auto sliced = [&](int len) -> size_t { return (size_t)len * SPT < CS ? (size_t)len * SPT : CS; };
+    if (n > CH && CH <= 32) {
+        // the chunk walk steps by chunk - 16 and its output bound (n + chunk) frames needs chunk > 32; the
+        // reference's models are traced at 64 or 256 (scripts/export_vocoder_traced.py)
+        Q3_LOG("voc_synthesize: chunk_tokens=%d is too short for the 16-frame overlap walk (need > 32)", CH);
+        return -1;
+    }
     std::vector<int64_t> padded((size_t)CH * 16);
     std::vector<float>& chunk = v->h_chunk;
     auto run_chunk = [&](int start, int len) -> int {
@@ -1834,8 +1947,8 @@ int voc_synthesize_f32(void* vv, const int64_t* codes, int n, float* out, int32_
     };
     if (n <= CH) {
         if (run_chunk(0, n)) return -1;
-        memcpy(out, chunk.data(), sizeof(float) * (size_t)n * SPT);
-        *n_samples = n * SPT;
+        memcpy(out, chunk.data(), sizeof(float) * sliced(n));
+        *n_samples = (int32_t)sliced(n);
         return 0;
     }
     const int OVERLAP = 16, OV = OVERLAP * SPT, step = CH - OVERLAP;
@@ -1844,7 +1957,7 @@ int voc_synthesize_f32(void* vv, const int64_t* codes, int n, float* out, int32_
     for (int start = 0; start < n; start += step) {
         const int len = (start + CH <= n) ? CH : n - start;
         if (run_chunk(start, len)) return -1;
-        const size_t cl = (size_t)len * SPT;
+        const size_t cl = sliced(len);
         if (have + cl > capacity) {
             Q3_LOG("voc_synthesize: chunk walk would pass the output bound (%zu + %zu > %zu)", have, cl, capacity);
             return -1;

@@ -79,6 +79,7 @@ def load(path: str | None = None):
     _sig(lib, "voc_free", None, [c_void_p])
     _sig(lib, "voc_chunk_tokens", c_int, [c_void_p])
     _sig(lib, "voc_samples_per_token", c_int, [c_void_p])
+    _sig(lib, "voc_chunk_samples", c_int, [c_void_p])
     _sig(lib, "voc_decode", c_int, [c_void_p, i64p, c_int, f32p])
     _sig(lib, "voc_synthesize", c_int, [c_void_p, i64p, c_int, i16p, i32p])
     _sig(lib, "voc_synthesize_f32", c_int, [c_void_p, i64p, c_int, f32p, i32p])

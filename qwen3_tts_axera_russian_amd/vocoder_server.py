@@ -41,7 +41,9 @@ class VocoderServer:
         self._running = False
 
     def _inference_chunk(self, padded):
-        out = np.empty((1, self.max_tokens * SAMPLES_PER_TOKEN), np.float32)
+        # the model's output tensor: [1, voc_chunk_samples] (<= max_tokens * SAMPLES_PER_TOKEN: the decoder family's
+        # transposed convs trim, include/qwen3tts_voc.h); callers slice it numpy-style like the reference does
+        out = np.empty((1, self._lib.voc_chunk_samples(self.h)), np.float32)
         c = np.ascontiguousarray(padded, np.int64)
         if self._lib.voc_decode(self.h, c.ctypes.data_as(hiplib.i64p), 1, hiplib.fptr(out)) != 0:
             raise RuntimeError("voc_decode failed")

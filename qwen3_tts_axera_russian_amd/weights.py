@@ -332,7 +332,7 @@ def from_hf_checkpoint(model_dir: str, out_path: str, cfg: ModelConfig | None = 
 # vocoder program (include/qwen3tts_voc.h, csrc/q3_voc.hip)
 # ----------------------------------------------------------------------------
 VOP_RVQ, VOP_CONV, VOP_CONVT = 1, 2, 3
-VOP_DWCONV, VOP_NORM, VOP_ATTN, VOP_GLU = 4, 5, 6, 7
+VOP_DWCONV, VOP_NORM, VOP_ATTN, VOP_GLU, VOP_EMBMEAN = 4, 5, 6, 7, 8
 VF_SNAKE, VF_RES_ADD, VF_RES_SAVE, VF_CLAMP, VF_GELU = 1, 2, 4, 8, 16
 
 
@@ -374,6 +374,17 @@ class VocConfig:
     convnext: bool = True
     convnext_kernel: int = 7
     convnext_eps_e9: int = 1000   # 1e-6
+    # --- what the importable implementation of this decoder family pins (transformers' Qwen3OmniMoeCode2Wav,
+    #     tests/golden/make_code2wav_golden.py) ---
+    # ConvTranspose1d trim.  "both" (default): kernel - stride samples are cut at BOTH ends, as
+    # Qwen3OmniMoeCausalTransConvNet does (left_pad = right_pad = k - s): a k = 2s block turns L columns into
+    # (L - 1) * s and output column j reads inputs j // s and j // s + 1.  "right": the strictly causal form (rounds 1-2:
+    # the first L * s outputs are kept).  The k = s upsamplers are the same under both.
+    convt_trim: str = "both"
+    front: str = "rvq"            # "rvq": split residual VQ de-quantiser; "embed": code_embedding(codes + q * size).mean(q)
+    pre_conv: bool = True         # causal conv front -> latent (the Omni class has none)
+    tf_proj: bool = True          # Linear input / output projections around the pre-transformer (the Omni class has none)
+    tf_attn_bias: bool = False    # q/k/v/o biases (config.attention_bias)
 
 
 def trunk_voc_config() -> VocConfig:
@@ -391,6 +402,15 @@ def tiny_full_voc_config() -> VocConfig:
                      tf_heads=4, tf_head_dim=16, tf_ffn=96, tf_window=24, convnext=True)
 
 
+def convt_trims(vc: VocConfig, k: int, stride: int):
+    """(left, right) samples cut from a ConvTranspose1d's (L - 1) * stride + k outputs."""
+    if vc.convt_trim == "both":
+        return k - stride, k - stride
+    if vc.convt_trim == "right":
+        return 0, k - stride
+    raise ValueError(f"convt_trim must be 'both' or 'right', not {vc.convt_trim!r}")
+
+
 def voc_program(vc: VocConfig):
     """-> list of (op, a, b, c, d, flags) rows + per-op tensor shapes."""
     prog, shapes = [], {}
@@ -401,9 +421,12 @@ def voc_program(vc: VocConfig):
         for n, shp in tens.items():
             shapes[f"voc.op{i}.{n}"] = shp
 
-    add([VOP_RVQ, vc.n_q, vc.codebook_size, vc.codebook_dim, vc.rvq_out],
-        {"codebook": (vc.n_q, vc.codebook_size, vc.codebook_dim), "proj_sem": (vc.rvq_out, vc.codebook_dim),
-         "proj_ac": (vc.rvq_out, vc.codebook_dim)})
+    if vc.front == "embed":
+        add([VOP_EMBMEAN, vc.n_q, vc.codebook_size, vc.rvq_out], {"embedding": (vc.n_q * vc.codebook_size, vc.rvq_out)})
+    else:
+        add([VOP_RVQ, vc.n_q, vc.codebook_size, vc.codebook_dim, vc.rvq_out],
+            {"codebook": (vc.n_q, vc.codebook_size, vc.codebook_dim), "proj_sem": (vc.rvq_out, vc.codebook_dim),
+             "proj_ac": (vc.rvq_out, vc.codebook_dim)})
 
     def conv(cin, cout, k, dil, flags):
         t = {"weight": (cout, cin, k), "bias": (cout,)}
@@ -415,7 +438,8 @@ def voc_program(vc: VocConfig):
         t = {"weight": (cin, cout, k), "bias": (cout,)}
         if flags & VF_SNAKE:
             t.update({"alpha": (cin,), "beta": (cin,)})
-        add([VOP_CONVT, cin, cout, k, stride, flags], t)
+        lt, rt = convt_trims(vc, k, stride)
+        add([VOP_CONVT, cin, cout, k, stride, flags, lt, rt], t)
 
     def linear(cin, cout, flags, bias=True):
         t = {"weight": (cout, cin, 1)}
@@ -429,21 +453,28 @@ def voc_program(vc: VocConfig):
             t["bias"] = (c,)
         add([VOP_NORM, c, c, kind, eps_e9, flags], t)
 
-    conv(vc.rvq_out, vc.latent, vc.pre_kernel, 1, 0)
+    if vc.pre_conv:
+        conv(vc.rvq_out, vc.latent, vc.pre_kernel, 1, 0)
+    elif vc.rvq_out != vc.latent:
+        raise ValueError(f"without a pre-conv the front's width {vc.rvq_out} must be the latent width {vc.latent}")
     if vc.pre_transformer_layers > 0:
         H, nh, hd, F = vc.tf_hidden, vc.tf_heads, vc.tf_head_dim, vc.tf_ffn
-        linear(vc.latent, H, 0)                                          # input projection
+        if vc.tf_proj:
+            linear(vc.latent, H, 0)                                      # input projection
+        elif H != vc.latent:
+            raise ValueError(f"without projections the transformer width {H} must be the latent width {vc.latent}")
         for _ in range(vc.pre_transformer_layers):
             norm(H, 0, vc.tf_eps_e9, VF_RES_SAVE)
-            linear(H, 3 * nh * hd, 0, bias=False)                        # q | k | v, head-major
+            linear(H, 3 * nh * hd, 0, bias=vc.tf_attn_bias)              # q | k | v, head-major
             add([VOP_ATTN, 3 * nh * hd, nh * hd, nh, hd, 0, vc.tf_window, vc.tf_rope_theta], {})
-            linear(nh * hd, H, VF_RES_ADD, bias=False)                   # o projection (x layer scale)
+            linear(nh * hd, H, VF_RES_ADD, bias=vc.tf_attn_bias)         # o projection (x layer scale)
             norm(H, 0, vc.tf_eps_e9, VF_RES_SAVE)
             linear(H, 2 * F, 0, bias=False)                              # gate | up
             add([VOP_GLU, 2 * F, F, 0], {})                              # silu(gate) * up
             linear(F, H, VF_RES_ADD, bias=False)                         # down projection (x layer scale)
         norm(H, 0, vc.tf_eps_e9, 0)
-        linear(H, vc.latent, 0)                                          # output projection
+        if vc.tf_proj:
+            linear(H, vc.latent, 0)                                      # output projection
     for f in vc.upsample_ratios:
         convt(vc.latent, vc.latent, f, f, 0)
         if vc.convnext:
@@ -479,6 +510,8 @@ def make_synthetic_voc(vc: VocConfig, seed: int = 1234) -> dict:
             a = 0.02 * rng.standard_normal(shp, dtype=np.float32)
         elif n.endswith("codebook"):
             a = 0.25 * rng.standard_normal(shp, dtype=np.float32)
+        elif n.endswith("embedding"):
+            a = rng.standard_normal(shp, dtype=np.float32)
         else:
             fan_in = int(np.prod(shp[1:])) if not n.endswith(("proj_sem", "proj_ac")) else shp[1]
             if ".weight" in n and len(shp) == 3 and prog[int(n.split(".")[1][2:])][0] == VOP_CONVT:
@@ -495,26 +528,54 @@ def make_synthetic_voc(vc: VocConfig, seed: int = 1234) -> dict:
 
 
 def voc_total_upsample(vc: VocConfig) -> int:
+    """decoder.total_upsample (scripts/export_vocoder_traced.py:46): the product of the rates -- the nominal samples
+    per frame; what a chunk really yields is voc_chunk_samples()."""
     u = 1
     for f in tuple(vc.upsample_ratios) + tuple(vc.rates):
         u *= f
     return u
 
 
+def voc_chunk_samples(vc: VocConfig, n_frames: int) -> int:
+    """Samples one decode of n_frames frames returns: every transposed conv maps L -> (L - 1) * s + k - trims."""
+    L = n_frames
+    for f in vc.upsample_ratios:
+        lt, rt = convt_trims(vc, f, f)
+        L = (L - 1) * f + f - lt - rt
+    for r in vc.rates:
+        lt, rt = convt_trims(vc, 2 * r, r)
+        L = (L - 1) * r + 2 * r - lt - rt
+    return L
+
+
 # ----------------------------------------------------------------------------
 # vocoder table from a speech_tokenizer/ directory (config.json + *.safetensors)
 # ----------------------------------------------------------------------------
 # The reference traces `Qwen3TTSTokenizerV2Model.from_pretrained(<speech_tokenizer dir>).decoder`
-# (scripts/export_vocoder_traced.py:74-79); neither the class nor a checkpoint is in the reference, so the tensor
-# NAMES below are recollection of that decoder's Mimi/BigVGAN-style module tree and live in ONE table a maintainer
-# edits; every SIZE (codebooks, widths, kernel sizes, rates, layer counts) is read from the tensors' shapes, nothing
-# about the architecture's dimensions is hard-coded.  Dilations and attention hyper-parameters that shapes cannot
-# show come from config.json's "decoder_config" (fallback: the defaults of VocConfig, flagged in the report).
+# (scripts/export_vocoder_traced.py:74-79); neither the class nor a checkpoint is in the reference.  What pins the
+# table since round 3: the importable implementation of this decoder family, transformers'
+# `Qwen3OmniMoeCode2Wav` (pre_transformer / upsample / decoder module tree, SnakeBeta, causal convs, the trim of the
+# transposed convs, ConvNeXt blocks, layer scales) and `MimiSplitResidualVectorQuantizer` (the split RVQ front):
+# tests/golden/make_code2wav_golden.py runs both on seeded weights, tests/test_code2wav_golden.py maps their
+# state_dict() keys through this converter and checks oracle/voc_ref.py (CPU) and voc_decode (GPU) against their
+# outputs.  The tensor NAMES live in ONE table; a value may list alternatives (first match wins): the module tree of
+# the Omni / Mimi classes as transformers names it, and the Qwen3-TTS-Tokenizer spelling of the quantiser / front
+# (recollection: `quantizer.rvq_first / rvq_rest`, `pre_conv`, `pre_transformer.input_proj / output_proj`).  Every SIZE
+# (codebooks, widths, kernel sizes, rates, layer counts) is read from the tensors' shapes; dilations and attention
+# hyper-parameters that shapes cannot show come from config.json's "decoder_config" (fallback: the defaults of
+# VocConfig, flagged in the report).
 VOC_NAMES = {
-    "codebook_first": "decoder.quantizer.rvq_first.vq.layers.{i}._codebook.embed",       # [size, dim]; or embed_sum / cluster_usage
-    "codebook_rest": "decoder.quantizer.rvq_rest.vq.layers.{i}._codebook.embed",
-    "proj_first": "decoder.quantizer.rvq_first.output_proj.weight",                      # [out, dim, 1]
-    "proj_rest": "decoder.quantizer.rvq_rest.output_proj.weight",
+    # split RVQ front ([size, dim] codebooks, or their EMA pair embed_sum / cluster_usage; projections [out, dim, 1])
+    "codebook_first": ("decoder.quantizer.rvq_first.vq.layers.{i}._codebook.",
+                       "decoder.quantizer.semantic_residual_vector_quantizer.layers.{i}.codebook."),
+    "codebook_rest": ("decoder.quantizer.rvq_rest.vq.layers.{i}._codebook.",
+                      "decoder.quantizer.acoustic_residual_vector_quantizer.layers.{i}.codebook."),
+    "proj_first": ("decoder.quantizer.rvq_first.output_proj.weight",
+                   "decoder.quantizer.semantic_residual_vector_quantizer.output_proj.weight"),
+    "proj_rest": ("decoder.quantizer.rvq_rest.output_proj.weight",
+                  "decoder.quantizer.acoustic_residual_vector_quantizer.output_proj.weight"),
+    # embedding-mean front of the Omni class: [n_q * size, hidden]
+    "code_embedding": "decoder.code_embedding.weight",
     "pre_conv": "decoder.pre_conv.conv",                                                 # .weight [latent, out, k] .bias
     "tf_in": "decoder.pre_transformer.input_proj", "tf_out": "decoder.pre_transformer.output_proj",
     "tf_norm": "decoder.pre_transformer.norm.weight",
@@ -541,10 +602,9 @@ def _load_safetensors_dir(src_dir: str) -> dict:
     return out
 
 
-def speech_tokenizer_to_voc(src_dir: str, names: dict | None = None):
+def speech_tokenizer_to_voc(src_dir: str, names: dict | None = None, convt_trim: str | None = None):
     """-> (VocConfig, tensors dict with voc.program + voc.op*.*, report lines).  See VOC_NAMES."""
     import json
-    N = dict(VOC_NAMES, **(names or {}))
     T = _load_safetensors_dir(src_dir)
     if not T:
         raise FileNotFoundError(f"no *.safetensors under {src_dir}")
@@ -554,22 +614,52 @@ def speech_tokenizer_to_voc(src_dir: str, names: dict | None = None):
         with open(cj) as f:
             j = json.load(f)
         cfgj = j.get("decoder_config", j)
+    return state_to_voc(T, cfgj, names, convt_trim, where=src_dir)
+
+
+def state_to_voc(T: dict, cfgj: dict | None = None, names: dict | None = None, convt_trim: str | None = None,
+                 where: str = "state dict"):
+    """A decoder state dict (numpy arrays under the checkpoint's names) + its config -> (VocConfig, table tensors,
+    report).  `convt_trim` overrides config.json's "convt_trim" ("both", the default = the Omni class's trim of the
+    transposed convs, or "right" = strictly causal; VocConfig)."""
+    cfgj = dict(cfgj or {})
+    N = dict(VOC_NAMES, **(names or {}))
     report = []
     f32 = lambda a: np.ascontiguousarray(np.asarray(a), dtype=np.float32)
     has = lambda k: k in T
+    used = set()
+    # a decoder.* module this table does not know (renamed, or a component this build has no op for) must not be
+    # dropped silently
+    known = {a.split(".")[1] for v in N.values() for a in (v if isinstance(v, (tuple, list)) else (v,)) if a.startswith("decoder.")}
+    strange = sorted({k.split(".")[1] for k in T if k.startswith("decoder.") and k.split(".")[1] not in known})
+    if strange:
+        raise KeyError(f"{where}: decoder modules {strange} are not in weights.VOC_NAMES (edit that table if the checkpoint "
+                       f"names things differently)")
+
+    def pick(key, **kw):
+        """the alternative of VOC_NAMES[key] that the checkpoint uses (first whose formatted prefix matches a tensor)"""
+        alts = N[key] if isinstance(N[key], (tuple, list)) else (N[key],)
+        for a in alts:
+            pre = a.format(**kw) if kw else a.split("{")[0]
+            if any(k.startswith(pre) for k in T):
+                return a
+        return alts[0]
 
     def need(k):
         if k not in T:
-            raise KeyError(f"{src_dir}: tensor {k} not found (edit weights.VOC_NAMES if the checkpoint names it differently)")
+            raise KeyError(f"{where}: tensor {k} not found (edit weights.VOC_NAMES if the checkpoint names it differently)")
+        used.add(k)
         return f32(T[k])
 
-    def codebook(key):
-        if has(key):
-            return need(key)
-        base = key[: -len("embed")]
-        if has(base + "embed_sum") and has(base + "cluster_usage"):   # EMA form: embed = embed_sum / usage
-            return f32(T[base + "embed_sum"]) / np.maximum(f32(T[base + "cluster_usage"]), 1e-5)[:, None]
-        raise KeyError(f"{src_dir}: codebook {key} (or its embed_sum / cluster_usage pair) not found")
+    def codebook(base):
+        for nm in ("embed", "embedding"):
+            if has(base + nm):
+                return need(base + nm)
+        for nm in ("embed_sum", "embedding_sum"):
+            if has(base + nm) and has(base + "cluster_usage"):   # EMA form: embed = embed_sum / usage.clamp(min=1e-5)
+                return need(base + nm) / np.maximum(need(base + "cluster_usage"), 1e-5)[:, None]
+        raise KeyError(f"{where}: codebook {base}embed (or its embed_sum / cluster_usage pair) not found "
+                       f"(edit weights.VOC_NAMES if the checkpoint names it differently)")
 
     def count(pattern, **kw):
         n = 0
@@ -577,12 +667,33 @@ def speech_tokenizer_to_voc(src_dir: str, names: dict | None = None):
             n += 1
         return n
 
-    # ---- sizes from shapes ----
-    n_rest = count(N["codebook_rest"].split("{i}")[0] + "{i}.")
-    cb0 = codebook(N["codebook_first"].format(i=0))
-    cbs = [cb0] + [codebook(N["codebook_rest"].format(i=i)) for i in range(n_rest)]
-    proj_sem, proj_ac = need(N["proj_first"]), need(N["proj_rest"])
-    pre_w = need(N["pre_conv"] + ".weight")
+    vc = VocConfig()
+    vc.convt_trim = convt_trim or str(cfgj.get("convt_trim", vc.convt_trim))
+    # ---- front ----
+    emb_key = pick("code_embedding")
+    vc.front = "embed" if has(emb_key) else "rvq"
+    if vc.front == "embed":
+        emb = need(emb_key)
+        vc.n_q = int(cfgj.get("num_quantizers", 16))
+        if emb.shape[0] % vc.n_q:
+            raise ValueError(f"{where}: code_embedding has {emb.shape[0]} rows, not a multiple of num_quantizers={vc.n_q}")
+        vc.codebook_size, vc.rvq_out, vc.codebook_dim = emb.shape[0] // vc.n_q, emb.shape[1], emb.shape[1]
+        if "num_quantizers" not in cfgj:
+            report.append(f"config.json has no num_quantizers: assuming {vc.n_q}")
+    else:
+        cb_first, cb_rest = pick("codebook_first", i=0), pick("codebook_rest", i=0)
+        n_rest = count(cb_rest)
+        cb0 = codebook(cb_first.format(i=0))
+        cbs = [cb0] + [codebook(cb_rest.format(i=i)) for i in range(n_rest)]
+        proj_sem, proj_ac = need(pick("proj_first")), need(pick("proj_rest"))
+        vc.n_q, vc.codebook_size, vc.codebook_dim = 1 + n_rest, cb0.shape[0], cb0.shape[1]
+        vc.rvq_out = proj_sem.shape[0]
+    vc.pre_conv = has(N["pre_conv"] + ".weight")
+    if vc.pre_conv:
+        pre_w = need(N["pre_conv"] + ".weight")
+        vc.latent, vc.pre_kernel = pre_w.shape[0], pre_w.shape[2]
+    else:
+        vc.latent = vc.rvq_out
     n_tf = count(N["tf_layer"])
     n_up = count(N["up_convt"].split("{i}")[0] + "{i}.")
     dec_in_w = need(N["dec_in"] + ".weight")
@@ -591,23 +702,35 @@ def speech_tokenizer_to_voc(src_dir: str, names: dict | None = None):
     while any(k.startswith(N["dec_block"].format(b=b)) for k in T):
         blocks.append(b)
         b += 1
-    out_b = b + 1 if any(k.startswith(N["dec_out"].format(b=b + 1)) for k in T) else b
-    vc = VocConfig()
-    vc.n_q, vc.codebook_size, vc.codebook_dim = 1 + n_rest, cb0.shape[0], cb0.shape[1]
-    vc.rvq_out, vc.latent, vc.pre_kernel = proj_sem.shape[0], pre_w.shape[0], pre_w.shape[2]
     vc.pre_transformer_layers = n_tf
+    kv_rep = 1
     if n_tf:
         lp = N["tf_layer"].format(i=0)
-        vc.tf_hidden = need(N["tf_in"] + ".weight").shape[0]
-        qd = need(lp + "self_attn.q_proj.weight").shape[0]
-        vc.tf_head_dim = int(cfgj.get("head_dim", cfgj.get("attention_head_dim", vc.tf_head_dim)))
+        vc.tf_proj = has(N["tf_in"] + ".weight")
+        q_w = need(lp + "self_attn.q_proj.weight")
+        vc.tf_hidden = q_w.shape[1]
+        qd, kd = q_w.shape[0], need(lp + "self_attn.k_proj.weight").shape[0]
+        if "head_dim" in cfgj or "attention_head_dim" in cfgj:
+            vc.tf_head_dim = int(cfgj.get("head_dim", cfgj.get("attention_head_dim")))
+        elif "num_attention_heads" in cfgj:
+            vc.tf_head_dim = qd // int(cfgj["num_attention_heads"])
+        else:
+            report.append(f"config.json has neither head_dim nor num_attention_heads: using head_dim {vc.tf_head_dim}")
         vc.tf_heads = qd // vc.tf_head_dim
+        if qd % vc.tf_head_dim or kd % vc.tf_head_dim or qd % kd:
+            raise ValueError(f"{where}: q/k projections of {qd}/{kd} rows do not split into heads of {vc.tf_head_dim}")
+        kv_rep = qd // kd        # grouped-query attention: every k/v head serves kv_rep query heads
         vc.tf_ffn = need(lp + "mlp.gate_proj.weight").shape[0]
-        for key, attr, scale in (("sliding_window", "tf_window", 1), ("rope_theta", "tf_rope_theta", 1)):
-            if key in cfgj:
-                setattr(vc, attr, int(cfgj[key] * scale))
-            else:
-                report.append(f"config.json has no {key}: using the default {getattr(vc, attr)}")
+        vc.tf_attn_bias = has(lp + "self_attn.q_proj.bias")
+        if "sliding_window" in cfgj:
+            vc.tf_window = int(cfgj["sliding_window"])
+        else:
+            report.append(f"config.json has no sliding_window: using the default {vc.tf_window}")
+        rp = cfgj.get("rope_parameters") or {}
+        if "rope_theta" in cfgj or "rope_theta" in rp:
+            vc.tf_rope_theta = int(cfgj.get("rope_theta", rp.get("rope_theta")))
+        else:
+            report.append(f"config.json has no rope_theta: using the default {vc.tf_rope_theta}")
         if "rms_norm_eps" in cfgj:
             vc.tf_eps_e9 = int(round(float(cfgj["rms_norm_eps"]) * 1e9))
     ups = [need(N["up_convt"].format(i=i) + ".weight") for i in range(n_up)]
@@ -645,31 +768,53 @@ def speech_tokenizer_to_voc(src_dir: str, names: dict | None = None):
             out[f"voc.op{i}.{n}"] = np.ascontiguousarray(a, dtype=np.float32)
 
     i = next(it)
-    put(i, codebook=np.stack(cbs), proj_sem=proj_sem.reshape(proj_sem.shape[0], -1), proj_ac=proj_ac.reshape(proj_ac.shape[0], -1))
-    put(next(it), weight=pre_w, bias=need(N["pre_conv"] + ".bias"))
+    if vc.front == "embed":
+        put(i, embedding=emb)
+    else:
+        put(i, codebook=np.stack(cbs), proj_sem=proj_sem.reshape(proj_sem.shape[0], -1), proj_ac=proj_ac.reshape(proj_ac.shape[0], -1))
+    if vc.pre_conv:
+        put(next(it), weight=pre_w, bias=need(N["pre_conv"] + ".bias"))
     if n_tf:
-        put(next(it), weight=lin(need(N["tf_in"] + ".weight")), bias=need(N["tf_in"] + ".bias"))
+        if vc.tf_proj:
+            put(next(it), weight=lin(need(N["tf_in"] + ".weight")), bias=need(N["tf_in"] + ".bias"))
+        hd = vc.tf_head_dim
+
+        def kv_heads(a):     # [kv_heads * hd, ...] -> [heads * hd, ...]: query head h reads k/v head h // kv_rep
+            if kv_rep == 1:
+                return a
+            return np.repeat(a.reshape((a.shape[0] // hd, hd) + a.shape[1:]), kv_rep, axis=0).reshape((-1,) + a.shape[1:])
+
         for l in range(n_tf):
             lp = N["tf_layer"].format(i=l)
-            sa = flat1(T[lp + "self_attn_layer_scale.scale"]) if has(lp + "self_attn_layer_scale.scale") else None
-            sm = flat1(T[lp + "mlp_layer_scale.scale"]) if has(lp + "mlp_layer_scale.scale") else None
+            sa = flat1(need(lp + "self_attn_layer_scale.scale")) if has(lp + "self_attn_layer_scale.scale") else None
+            sm = flat1(need(lp + "mlp_layer_scale.scale")) if has(lp + "mlp_layer_scale.scale") else None
             put(next(it), weight=need(lp + "input_layernorm.weight"))
-            put(next(it), weight=lin(np.concatenate([need(lp + f"self_attn.{x}_proj.weight") for x in "qkv"], 0)))
+            qkv = dict(weight=lin(np.concatenate([need(lp + "self_attn.q_proj.weight"), kv_heads(need(lp + "self_attn.k_proj.weight")),
+                                                  kv_heads(need(lp + "self_attn.v_proj.weight"))], 0)))
+            if vc.tf_attn_bias:
+                qkv["bias"] = np.concatenate([need(lp + "self_attn.q_proj.bias"), kv_heads(need(lp + "self_attn.k_proj.bias")),
+                                              kv_heads(need(lp + "self_attn.v_proj.bias"))], 0)
+            put(next(it), **qkv)
             next(it)                                                            # attention: no tensors
             o = need(lp + "self_attn.o_proj.weight")
-            put(next(it), weight=lin(o * sa[:, None] if sa is not None else o))  # layer scale folds into the rows
+            ot = dict(weight=lin(o * sa[:, None] if sa is not None else o))     # layer scale folds into the rows
+            if vc.tf_attn_bias:
+                ob = need(lp + "self_attn.o_proj.bias")
+                ot["bias"] = ob * sa if sa is not None else ob
+            put(next(it), **ot)
             put(next(it), weight=need(lp + "post_attention_layernorm.weight"))
             put(next(it), weight=lin(np.concatenate([need(lp + "mlp.gate_proj.weight"), need(lp + "mlp.up_proj.weight")], 0)))
             next(it)                                                            # GLU: no tensors
             d = need(lp + "mlp.down_proj.weight")
             put(next(it), weight=lin(d * sm[:, None] if sm is not None else d))
         put(next(it), weight=need(N["tf_norm"]))
-        put(next(it), weight=lin(need(N["tf_out"] + ".weight")), bias=need(N["tf_out"] + ".bias"))
+        if vc.tf_proj:
+            put(next(it), weight=lin(need(N["tf_out"] + ".weight")), bias=need(N["tf_out"] + ".bias"))
     for u in range(n_up):
         put(next(it), weight=ups[u], bias=need(N["up_convt"].format(i=u) + ".bias"))
         if vc.convnext:
             p = N["up_next"].format(i=u)
-            g = flat1(T[p + "gamma"]) if has(p + "gamma") else None
+            g = flat1(need(p + "gamma")) if has(p + "gamma") else None
             put(next(it), weight=need(p + "dwconv.conv.weight"), bias=need(p + "dwconv.conv.bias"))
             put(next(it), weight=need(p + "norm.weight"), bias=need(p + "norm.bias"))
             put(next(it), weight=lin(need(p + "pwconv1.weight")), bias=need(p + "pwconv1.bias"))
@@ -690,16 +835,28 @@ def speech_tokenizer_to_voc(src_dir: str, names: dict | None = None):
     missing = [n for n in shapes if n not in out]
     if missing:
         raise ValueError(f"table tensors without a source: {missing[:5]}")
-    report.insert(0, f"{len(prog)} ops: {vc.n_q} codebooks x {vc.codebook_size} x {vc.codebook_dim} -> {vc.rvq_out}, latent {vc.latent}, "
-                     f"{n_tf} transformer layers (hidden {vc.tf_hidden}, {vc.tf_heads} x {vc.tf_head_dim}, ffn {vc.tf_ffn}), "
+    unused = sorted(k for k in T if k.startswith("decoder.") and k not in used and
+                    not k.endswith(("initialized", "_initialized", "rotary_emb.inv_freq")) and
+                    not (".quantizer." in k and ".input_proj." in k))      # the quantiser's encode-side projection
+    if unused:
+        raise KeyError(f"{where}: {len(unused)} decoder tensors have no place in the table (first: {unused[:4]}); a component "
+                       f"this build has no op for, or a name weights.VOC_NAMES lacks")
+    front = (f"{vc.n_q} x {vc.codebook_size} embedding rows averaged -> {vc.rvq_out}" if vc.front == "embed" else
+             f"{vc.n_q} codebooks x {vc.codebook_size} x {vc.codebook_dim} -> {vc.rvq_out}")
+    report.insert(0, f"{len(prog)} ops: {front}, latent {vc.latent}{'' if vc.pre_conv else ' (no pre-conv)'}, "
+                     f"{n_tf} transformer layers (hidden {vc.tf_hidden}, {vc.tf_heads} x {vc.tf_head_dim}"
+                     f"{f' from {vc.tf_heads // kv_rep} k/v heads' if kv_rep > 1 else ''}, ffn {vc.tf_ffn}"
+                     f"{'' if vc.tf_proj or not n_tf else ', no in/out projections'}), "
                      f"upsample {vc.upsample_ratios}{' + ConvNeXt' if vc.convnext else ''}, decoder {vc.decoder_dim} rates {vc.rates} "
-                     f"dilations {vc.dilations} k{vc.kernel}: x{voc_total_upsample(vc)} samples per frame")
+                     f"dilations {vc.dilations} k{vc.kernel}: x{voc_total_upsample(vc)} samples per frame nominal, "
+                     f"transposed convs trimmed '{vc.convt_trim}' ({voc_chunk_samples(vc, 64)} samples per 64 frames)")
     return vc, out, report
 
 
-def convert_speech_tokenizer(src_dir: str, out_path: str, chunk: int = 64, names: dict | None = None):
+def convert_speech_tokenizer(src_dir: str, out_path: str, chunk: int = 64, names: dict | None = None,
+                             convt_trim: str | None = None):
     """speech_tokenizer/ (config.json + safetensors) -> vocoder container for voc_load()."""
-    vc, t, report = speech_tokenizer_to_voc(src_dir, names)
+    vc, t, report = speech_tokenizer_to_voc(src_dir, names, convt_trim)
     write_pack(out_path, {"voc_chunk": float(chunk)}, t)
     return vc, report
 
@@ -710,28 +867,33 @@ def export_speech_tokenizer_layout(tensors: dict, vc: VocConfig, dst_dir: str, l
     their own tensors -- divided out of the folded weights -- and an EMA-form first codebook)."""
     import json
     from safetensors.numpy import save_file
-    N = VOC_NAMES
+    N = {k: (v[0] if isinstance(v, tuple) else v) for k, v in VOC_NAMES.items()}
     prog, _ = voc_program(vc)
     rng = np.random.default_rng(seed)
     out = {}
     g = lambda i, n: np.asarray(tensors[f"voc.op{i}.{n}"], dtype=np.float32)
     it = iter(range(len(prog)))
     i = next(it)
-    cb = g(i, "codebook")
-    usage = (1.0 + rng.random(cb.shape[1])).astype(np.float32)
-    base = N["codebook_first"].format(i=0)[: -len("embed")]
-    out[base + "embed_sum"] = cb[0] * usage[:, None]
-    out[base + "cluster_usage"] = usage
-    for q in range(1, cb.shape[0]):
-        out[N["codebook_rest"].format(i=q - 1)] = cb[q]
-    out[N["proj_first"]] = g(i, "proj_sem")[:, :, None]
-    out[N["proj_rest"]] = g(i, "proj_ac")[:, :, None]
-    i = next(it)
-    out[N["pre_conv"] + ".weight"], out[N["pre_conv"] + ".bias"] = g(i, "weight"), g(i, "bias")
+    if vc.front == "embed":
+        out[N["code_embedding"]] = g(i, "embedding")
+    else:
+        cb = g(i, "codebook")
+        usage = (1.0 + rng.random(cb.shape[1])).astype(np.float32)
+        base = N["codebook_first"].format(i=0)
+        out[base + "embed_sum"] = cb[0] * usage[:, None]
+        out[base + "cluster_usage"] = usage
+        for q in range(1, cb.shape[0]):
+            out[N["codebook_rest"].format(i=q - 1) + "embed"] = cb[q]
+        out[N["proj_first"]] = g(i, "proj_sem")[:, :, None]
+        out[N["proj_rest"]] = g(i, "proj_ac")[:, :, None]
+    if vc.pre_conv:
+        i = next(it)
+        out[N["pre_conv"] + ".weight"], out[N["pre_conv"] + ".bias"] = g(i, "weight"), g(i, "bias")
     if vc.pre_transformer_layers:
         H, qd, F = vc.tf_hidden, vc.tf_heads * vc.tf_head_dim, vc.tf_ffn
-        i = next(it)
-        out[N["tf_in"] + ".weight"], out[N["tf_in"] + ".bias"] = g(i, "weight")[:, :, 0], g(i, "bias")
+        if vc.tf_proj:
+            i = next(it)
+            out[N["tf_in"] + ".weight"], out[N["tf_in"] + ".bias"] = g(i, "weight")[:, :, 0], g(i, "bias")
         for l in range(vc.pre_transformer_layers):
             lp = N["tf_layer"].format(i=l)
             out[lp + "input_layernorm.weight"] = g(next(it), "weight")
@@ -752,8 +914,9 @@ def export_speech_tokenizer_layout(tensors: dict, vc: VocConfig, dst_dir: str, l
             if layer_scales:
                 out[lp + "self_attn_layer_scale.scale"], out[lp + "mlp_layer_scale.scale"] = sa, sm
         out[N["tf_norm"]] = g(next(it), "weight")
-        i = next(it)
-        out[N["tf_out"] + ".weight"], out[N["tf_out"] + ".bias"] = g(i, "weight")[:, :, 0], g(i, "bias")
+        if vc.tf_proj:
+            i = next(it)
+            out[N["tf_out"] + ".weight"], out[N["tf_out"] + ".bias"] = g(i, "weight")[:, :, 0], g(i, "bias")
     for u in range(len(vc.upsample_ratios)):
         i = next(it)
         out[N["up_convt"].format(i=u) + ".weight"], out[N["up_convt"].format(i=u) + ".bias"] = g(i, "weight"), g(i, "bias")
@@ -791,4 +954,5 @@ def export_speech_tokenizer_layout(tensors: dict, vc: VocConfig, dst_dir: str, l
     with open(os.path.join(dst_dir, "config.json"), "w") as f:
         json.dump({"model_type": "qwen3_tts_tokenizer_12hz", "decoder_config": {
             "head_dim": vc.tf_head_dim, "sliding_window": vc.tf_window, "rope_theta": vc.tf_rope_theta,
-            "rms_norm_eps": vc.tf_eps_e9 * 1e-9, "dilations": list(vc.dilations)}}, f)
+            "rms_norm_eps": vc.tf_eps_e9 * 1e-9, "dilations": list(vc.dilations), "num_quantizers": vc.n_q,
+            "convt_trim": vc.convt_trim}}, f)

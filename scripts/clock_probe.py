@@ -10,7 +10,7 @@ lib.voc_set_exact_fp32(1)
 B = 32
 h = lib.voc_load(path.encode(), 64, B)
 codes = np.random.default_rng(0).integers(0, 2048, size=(B, 64, 16)).astype(np.int64)
-out = np.empty((B, 64 * 1920), np.float32)
+out = np.empty((B, lib.voc_chunk_samples(h)), np.float32)
 stop = False
 samples = []
 def poll():

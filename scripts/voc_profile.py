@@ -38,7 +38,7 @@ def main():
     assert h
     B = a.batch
     codes = np.random.default_rng(0).integers(0, 2048, size=(B, 64, 16)).astype(np.int64)
-    out = np.empty((B, 64 * 1920), np.float32)
+    out = np.empty((B, lib.voc_chunk_samples(h)), np.float32)
     for _ in range(2):
         assert lib.voc_decode(h, codes.ctypes.data_as(hiplib.i64p), B, hiplib.fptr(out)) == 0
     total_ms = lib.voc_last_decode_ms(h)

@@ -265,6 +265,23 @@ for n in ns:
     idx = np.linspace(0, len(out) - 1, 64).astype(np.int64)
     G[f"voc_{n}_probe"] = out[idx]
 
+# a model that returns FEWER than 64 x 1920 samples per chunk -- what the traced decoder does if its transposed convs
+# trim at both ends like the importable member of its family (Qwen3OmniMoeCausalTransConvNet: 64 frames -> 122 325
+# samples; tests/golden/make_code2wav_golden.py): the reference's slices `audio[:n * 1920]` then follow numpy's rule
+# (vocoder_server.py:81,98-99).  Three lengths: the family's 122 325, a chunk shorter than the 16-frame overlap region
+# would need for the last tokens (60 * 1920 + 7), and one shorter than the overlap itself (15 * 1920 + 5).
+G["vocshort_lens"] = np.array([122325, 60 * 1920 + 7, 15 * 1920 + 5])
+G["vocshort_ns"] = np.array([1, 63, 64, 65, 80, 97, 112, 150, 750])
+for cs in (int(x) for x in G["vocshort_lens"]):
+    vsrv._inference_chunk = lambda padded, cs=cs: stub_chunk(padded)[:cs]
+    srng = np.random.default_rng(53)
+    for n in (int(x) for x in G["vocshort_ns"]):
+        codes = srng.integers(0, 2048, size=(n, 16)).astype(np.int64)
+        out = vsrv.synthesize(codes)
+        G[f"vocshort_{cs}_{n}_len"] = np.array(len(out))
+        G[f"vocshort_{cs}_{n}_sha"] = np.array(sha(np.ascontiguousarray(out, dtype=np.float32)))
+vsrv._inference_chunk = stub_chunk
+
 # ----------------------------------------------------------------------------- vocoder server over a real socket
 sock_path = os.path.join(tempfile.mkdtemp(), "voc.sock")
 vsrv.socket_path, vsrv._running = sock_path, True

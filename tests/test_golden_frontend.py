@@ -151,6 +151,22 @@ def test_vocoder_chunking_matches_reference(golden):
     assert int(golden["voc_96_len"]) == 96 * 1920
 
 
+def test_vocoder_chunking_with_a_model_that_returns_short_chunks(golden):
+    """`audio[:n * 1920]` of a chunk shorter than 64 x 1920 samples is as long as what is there (numpy slicing):
+    the reference's own synthesize run on stubs returning 122 325 (the decoder family's 64-frame length),
+    60 x 1920 + 7 and 15 x 1920 + 5 samples (vocoder_server.py:81,98-99,104-117)."""
+    for cs in (int(x) for x in golden["vocshort_lens"]):
+        srng = np.random.default_rng(53)
+        for n in (int(x) for x in golden["vocshort_ns"]):
+            codes = srng.integers(0, 2048, size=(n, 16)).astype(np.int64)
+            out = fe.voc_synthesize(codes, lambda p: _stub_chunk(p)[:cs], 64)
+            assert len(out) == int(golden[f"vocshort_{cs}_{n}_len"]), (cs, n)
+            assert hashlib.sha256(np.ascontiguousarray(out, dtype=np.float32).tobytes()).hexdigest() == \
+                str(golden[f"vocshort_{cs}_{n}_sha"]), (cs, n)
+    assert int(golden["vocshort_122325_64_len"]) == 122325 and int(golden["vocshort_122325_63_len"]) == 63 * 1920
+    assert int(golden["vocshort_28805_65_len"]) == 2 * 28805      # shorter than the overlap: plain concatenation
+
+
 def test_int16_rule_matches_reference_server(golden):
     codes = golden["vocsrv_codes"]
     audio = fe.voc_synthesize(codes, lambda p: _stub_chunk(p) * 8.0 - 4.5, 64)

@@ -79,7 +79,7 @@ def test_vocoder_request_bounds(gpu_lib):
     h = lib.voc_load(path.encode(), 64, 2)
     assert h
     codes = np.zeros((3, 64, 16), np.int64)
-    out = np.full((3, 64 * 1920), 5.0, np.float32)
+    out = np.full((3, 64 * 1920), 5.0, np.float32)     # (>= 3 rows of voc_chunk_samples)
     assert lib.voc_decode(h, codes.ctypes.data_as(hiplib.i64p), 3, fp(out)) == -1     # beyond max_batch
     assert lib.voc_decode(h, codes.ctypes.data_as(hiplib.i64p), 0, fp(out)) == -1
     assert (out == 5.0).all()

@@ -120,7 +120,7 @@ def test_batch_server_matches_single_utterance_path(gpu_lib, packs, tmp_path):
         np.testing.assert_array_equal(codes, ecodes[:n, b, :])
         assert (codes >= 0).all() and (codes < 2048).all()
         np.testing.assert_array_equal(pcm, vs.synthesize_int16(codes.astype(np.int64)))
-        assert len(pcm) >= n * 1920
+        assert len(pcm) >= min(n, 63) * 1920          # (a full 64-frame chunk is 122 325 samples: the family's trim)
     assert len({int(x) for x in per}) > 1          # the utterances really ended at different frames
     # more utterances than slots: continuous batching (q3e_refill) -- every utterance comes back, in request order,
     # with the codes it gets in a batch of its own (slots are independent; greedy decode)
@@ -140,7 +140,7 @@ def test_batch_server_matches_single_utterance_path(gpu_lib, packs, tmp_path):
         np.testing.assert_array_equal(res6[i][1], vs.synthesize_int16(q[k].astype(np.int64)))
     assert abs(len(res6[0][0]) - len(res[0][0])) <= 8 and abs(len(res6[2][0]) - len(res[3][0])) <= 8
     for codes, pcm in res6:
-        assert codes.shape[0] >= 1 and (codes >= 0).all() and (codes < 2048).all() and len(pcm) >= codes.shape[0] * 1920
+        assert codes.shape[0] >= 1 and (codes >= 0).all() and (codes < 2048).all() and len(pcm) >= min(codes.shape[0], 63) * 1920
     # an empty request -> error sentinel; the next request is served
     s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
     s.connect(sock)

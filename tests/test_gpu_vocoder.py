@@ -35,11 +35,12 @@ class Voc:
         self.h = lib.voc_load(path.encode(), chunk, max_batch)
         assert self.h
         self.chunk, self.spt = lib.voc_chunk_tokens(self.h), lib.voc_samples_per_token(self.h)
+        self.cs = lib.voc_chunk_samples(self.h)      # what a decode returns per chunk (<= chunk * spt)
 
     def decode(self, codes):
         codes = np.ascontiguousarray(codes, np.int64)
         B = codes.shape[0]
-        out = np.empty((B, self.chunk * self.spt), np.float32)
+        out = np.empty((B, self.cs), np.float32)
         assert self.lib.voc_decode(self.h, codes.ctypes.data_as(hiplib.i64p), B, hiplib.fptr(out)) == 0
         return out
 
@@ -69,13 +70,14 @@ def test_decode_matches_torch_reference(gpu_lib, tiny_voc, exact):
     gpu_lib.voc_set_exact_fp32(exact)
     v = Voc(gpu_lib, path)
     assert v.chunk == 64 and v.spt == 1920 == W.voc_total_upsample(vc)
+    assert v.cs == W.voc_chunk_samples(vc, 64) == 122325      # the decoder family's trim: 64 frames -> 122 325 samples
     rng = np.random.default_rng(3)
     codes = rng.integers(0, 2048, size=(3, 64, 16)).astype(np.int64)
     codes[2, 40:] = 0                      # the server's zero padding of a short chunk
     codes[1, 5, 3] = 5000                  # out-of-range id embeds as zeros
     got = v.decode(codes)
     ref = voc_reference(tensors, codes)
-    assert got.shape == ref.shape == (3, 122880)
+    assert got.shape == ref.shape == (3, 122325)
     err = np.abs(got - ref).max()
     print("vocoder max abs err:", err, "ref max:", np.abs(ref).max(), "clamped frac:", float((np.abs(ref) >= 1).mean()))
     assert np.abs(ref).max() > 0.05        # a live signal, not silence
@@ -117,14 +119,77 @@ def test_synthesize_chunk_walk_and_int16(gpu_lib, tiny_voc):
         assert len(got) == len(want), n
         np.testing.assert_array_equal(got, want)
         np.testing.assert_array_equal(v.synth_i16(codes), fe.to_int16(want))
-    assert len(v.synth_f32(np.zeros((150, 16), np.int64))) == 156 * 1920
+    # the lengths the reference's own synthesize produces around a model that returns 122 325 samples per chunk
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frontend_golden.npz"))
+    for n in (int(x) for x in gold["vocshort_ns"]):
+        assert len(v.synth_f32(np.zeros((n, 16), np.int64))) == int(gold[f"vocshort_122325_{n}_len"]), n
     v.close()
 
 
+def test_strictly_causal_trim_is_a_table_parameter(gpu_lib, tmp_path):
+    """`convt_trim="right"` (rounds 1-2): the transposed convs keep their first L * stride outputs -- 1920 samples per
+    frame exactly; same kernels, other trims in the table rows.  Decode + chunk walk against the oracle."""
+    vc = W.tiny_voc_config()
+    vc.convt_trim = "right"
+    t = W.make_synthetic_voc(vc, seed=7)
+    path = str(tmp_path / "voc_right.q3w")
+    W.write_pack(path, {"voc_chunk": 64.0}, t)
+    for exact in (1, 0):
+        gpu_lib.voc_set_exact_fp32(exact)
+        v = Voc(gpu_lib, path, max_batch=2)
+        assert v.cs == 64 * 1920 == W.voc_chunk_samples(vc, 64)
+        codes = np.random.default_rng(8).integers(0, 2048, size=(2, 64, 16)).astype(np.int64)
+        got, ref = v.decode(codes), voc_reference(t, codes)
+        assert got.shape == ref.shape == (2, 122880) and np.abs(ref).max() > 0.05
+        assert np.abs(got - ref).max() < 2e-4
+        assert len(v.synth_f32(np.zeros((150, 16), np.int64))) == 156 * 1920      # the reference's length quirk, full chunks
+        v.close()
+    gpu_lib.voc_set_exact_fp32(0)
+
+
+@pytest.mark.parametrize("name", ["omni", "omni_b", "tts"])
+def test_code2wav_golden_on_the_gpu(gpu_lib, tmp_path, name):
+    """voc_decode against the outputs of the importable implementation of the reference's vocoder family
+    (transformers' Qwen3OmniMoeCode2Wav; Mimi split RVQ front in the "tts" case) stored by
+    tests/golden/make_code2wav_golden.py: state-dict keys -> weights.state_to_voc -> container -> voc_load at the
+    fixture's own frame count -> waveform, in both arithmetic modes, 2e-4 of full scale; stage activations through
+    voc_debug_run.  (CPU twin: tests/test_code2wav_golden.py, 1e-5.)"""
+    import ctypes
+    from tests import c2w_common as C
+    from tests.test_code2wav_golden import load_case
+    case, vc, tens, codes, gold, _ = load_case(name)
+    path = str(tmp_path / f"c2w_{name}.q3w")
+    W.write_pack(path, {"voc_chunk": float(case["T"])}, tens)
+    lib = gpu_lib
+    lib.voc_debug_run.restype = ctypes.c_int
+    lib.voc_debug_run.argtypes = [ctypes.c_void_p, hiplib.i64p, ctypes.c_int, ctypes.c_int, hiplib.f32p, hiplib.i32p, hiplib.i32p]
+    for exact in (1, 0):
+        lib.voc_set_exact_fp32(exact)
+        v = Voc(lib, path, chunk=case["T"], max_batch=1)
+        assert v.chunk == case["T"] and v.cs == gold["wav"].shape[0] and v.spt == W.voc_total_upsample(vc)
+        wav = v.decode(codes)[0]
+        err = float(np.abs(wav - gold["wav"]).max())
+        print(f"{name} exact={exact}: waveform max abs err vs the golden {err:.2e} (signal max {np.abs(gold['wav']).max():.2f})")
+        assert err < 2e-4
+        for stage, n_ops in C.stage_ops(vc, tens["voc.program"]).items():
+            want = gold[stage]
+            Cc, L = np.zeros(1, np.int32), np.zeros(1, np.int32)
+            buf = np.empty(want.shape[0] * 20000, np.float32)
+            assert lib.voc_debug_run(v.h, codes.ctypes.data_as(hiplib.i64p), 1, n_ops, hiplib.fptr(buf), hiplib.iptr(Cc), hiplib.iptr(L)) == 0
+            act = buf[: int(Cc[0]) * int(L[0])].reshape(int(Cc[0]), int(L[0]))
+            got = act[:, C.column_subset(act.shape[1])]
+            assert got.shape == want.shape, (stage, act.shape)
+            e = float(np.abs(got - want).max() / max(1.0, float(np.abs(want).max())))
+            assert e < 2e-4, (name, exact, stage, e)
+        v.close()
+    lib.voc_set_exact_fp32(0)
+
+
 def test_full_size_table_is_causal_and_deterministic(gpu_lib, tmp_path_factory):
-    """Size-independent properties at the full default table (307 GFLOP per 64-frame chunk, the bench's
-    vocoder): every convolution is causal, so the first 48 frames' samples must not change -- bit for bit --
-    when the last 16 frames' codes do (what chunked streaming with overlap relies on, vocoder_server.py:84-117);
+    """Size-independent properties at the full default table (the bench's vocoder): every op looks back only
+    (but for the one-column look-ahead of the transposed convs), so the first 47 frames' samples must not change
+    -- bit for bit -- when the last 16 frames' codes do (what chunked streaming with overlap relies on,
+    vocoder_server.py:84-117);
     a chunk decodes to the same samples alone and inside a batch; and twice the same input gives the same bits."""
     path = os.path.join(CACHE, "voc_whole_s1234.q3w")
     if not os.path.exists(path):
@@ -137,7 +202,9 @@ def test_full_size_table_is_causal_and_deterministic(gpu_lib, tmp_path_factory):
     c = rng.integers(0, 2048, size=(64, 16)).astype(np.int64)
     out = v.decode(np.stack([a, b, c])).copy()
     assert np.abs(out).max() > 0.01 and np.isfinite(out).all()
-    np.testing.assert_array_equal(out[0, :48 * 1920], out[1, :48 * 1920])
+    # (the family's transposed convs look ONE input column ahead per block -- a quarter frame in all -- so the first
+    # 47 frames are the ones that cannot see frame 48)
+    np.testing.assert_array_equal(out[0, :47 * 1920], out[1, :47 * 1920])
     assert not np.array_equal(out[0, 48 * 1920:], out[1, 48 * 1920:])
     np.testing.assert_array_equal(v.decode(a[None])[0], out[0])          # alone == inside a batch
     np.testing.assert_array_equal(v.decode(np.stack([a, b, c])), out)    # deterministic
@@ -162,7 +229,7 @@ def test_full_size_table_matches_torch_reference_in_both_arithmetic_modes(gpu_li
     rng = np.random.default_rng(21)
     codes = rng.integers(0, 2048, size=(2, 64, 16)).astype(np.int64)
     ref = voc_reference(tensors, codes)
-    assert ref.shape == (2, 64 * 1920) and np.abs(ref).max() > 0.01
+    assert ref.shape == (2, 122325) and np.abs(ref).max() > 0.01
     for exact in (1, 0):
         gpu_lib.voc_set_exact_fp32(exact)
         v = Voc(gpu_lib, path, max_batch=2)
