@@ -35,8 +35,10 @@ from .weights import ModelConfig, read_pack
 class BatchSynthesisServer:
     def __init__(self, model_path, vocoder_path, socket_path="/tmp/qwen3_batch.sock", max_batch=32, n_ctx=512,
                  max_tokens=200, temperature=0.0, top_k=50, cp_temperature=0.0, tokenizer=None, seed=0,
-                 install_signal_handlers=True):
+                 install_signal_handlers=True, max_request=None):
         self.socket_path, self.max_batch, self.max_tokens = socket_path, max_batch, max_tokens
+        # utterances one request may queue (the server is single-threaded: an unbounded request holds it indefinitely)
+        self.max_request = int(max_request) if max_request else 8 * max_batch
         meta, t = read_pack(model_path)
         self.cfg = ModelConfig.from_meta(meta)
         f32 = lambda n: np.asarray(t[n], dtype=np.float32)
@@ -74,6 +76,8 @@ class BatchSynthesisServer:
         B = len(token_ids)
         if B == 0:
             raise ValueError("a request needs at least one utterance")
+        if B > self.max_request:
+            raise ValueError(f"a request may carry at most {self.max_request} utterances (got {B})")
         max_tokens = min(int(max_tokens or self.max_tokens), self.max_tokens)
         prefixes = [self.front.build_prefix(ids) for ids in token_ids]
         if max(p.shape[0] for p in prefixes) + max_tokens > self.n_ctx:

@@ -183,35 +183,25 @@ void ModelCfg::from_pack(const Pack& p) {
 
 }  // namespace q3
 
-namespace q3 {
-bool cu_partition_mask(bool complement, std::vector<uint32_t>& mask) {
-    const char* e = getenv("Q3_VOC_CUS");
-    const int n_voc = e ? atoi(e) : 0;
-    hipDeviceProp_t prop;
-    int dev = 0;
-    if (n_voc <= 0 || hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
-    const int total = prop.multiProcessorCount;
-    if (n_voc >= total) return false;
-    mask.assign((total + 31) / 32, 0u);
-    for (int i = 0; i < n_voc; i++) {      // every k-th CU: each XCD / shader engine contributes equally
-        const int cu = (int)((long long)i * total / n_voc);
-        mask[cu / 32] |= 1u << (cu % 32);
-    }
-    if (complement)
-        for (int cu = 0; cu < total; cu++) mask[cu / 32] ^= 1u << (cu % 32);
-    return true;
-}
-}  // namespace q3
-
 // ---- HIP runtime configuration, applied when the library is loaded (before the runtime initialises: it reads its
 // flags at the first HIP call of the process) ----
 // GPU_MAX_HW_QUEUES=1: every stream of the process shares ONE hardware queue.  Measured on MI355X / ROCm 7.2
 // ("one hardware queue"): the replayed frame graph is 8-9 % faster (2.69 -> 2.46 ms per frame at 32 rows,
 // 2.49 -> 2.23 at one) -- the command processor has one queue to service between dependent nodes -- and nothing is lost:
-// kernels of the frame loop and of the vocoder do not overlap on this chip anyway (waves that issue MFMA chains starve
-// co-resident short kernels; the step time is the serial sum with any number of queues).  A value already set by the
-// user wins.
-__attribute__((constructor)) static void q3_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "1", 0); }
+// kernels of the frame loop and of the vocoder do not overlap on this chip anyway (the step time is the serial sum with
+// any number of queues).  This is a PROCESS-WIDE policy of the HIP runtime, so it is the host program's to decide: the
+// Python entry points (hiplib.load, the servers, bench.py) export the variable themselves before anything initialises
+// HIP.  For a host that dlopens this library directly -- the reference's llama_cpp_bindings.py loading it as
+// llama_wrapper.so, a C++ server -- the constructor below does it, says so on stderr once, and stands back when the user
+// has chosen a value or exported Q3_KEEP_HW_QUEUES=1 (co-hosting another HIP engine that wants its own queues).
+__attribute__((constructor)) static void q3_runtime_defaults() {
+    if (getenv("GPU_MAX_HW_QUEUES")) return;                                    // the user's (or the entry point's) value wins
+    if (const char* k = getenv("Q3_KEEP_HW_QUEUES"))
+        if (atoi(k) != 0) return;
+    setenv("GPU_MAX_HW_QUEUES", "1", 0);
+    fprintf(stderr, "[qwen3tts] GPU_MAX_HW_QUEUES=1 set for this process (one HIP hardware queue: -9 %% per frame step; export "
+                    "GPU_MAX_HW_QUEUES or Q3_KEEP_HW_QUEUES=1 to keep the runtime's default)\n");
+}
 
 // ---- device selection (include/qwen3tts_engine.h): one process per GPU ----
 extern "C" int q3_device_count(void) {

@@ -92,12 +92,6 @@ inline float bf16_to_f32(uint16_t b) {
 float h2f(uint16_t h);
 uint16_t f2h_sat(float f);
 
-// CU partition between the vocoder (throughput work) and the frame loop (a latency-bound chain of short kernels):
-// Q3_VOC_CUS=n gives the vocoder's stream n compute units spread evenly over the XCDs (every k-th CU) and the frame
-// loop's streams the others, so neither waits for the other's workgroups to retire.  Returns false when the
-// variable is unset / out of range (no partition); `complement` selects the frame loop's side.
-bool cu_partition_mask(bool complement, std::vector<uint32_t>& mask);
-
 struct ModelCfg {
     int hidden = 1024, head_dim = 128, n_heads = 16, n_kv = 8;
     int talker_layers = 28, talker_ffn = 3072, talker_vocab = 3072;

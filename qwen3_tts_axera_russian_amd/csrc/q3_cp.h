@@ -18,7 +18,7 @@ struct CpFrameIO {
     float temperature = 0.f;
     int top_k = 50;
     unsigned long long seed = 0;
-    const unsigned long long* seed_ptr = nullptr;  // device scalar overriding `seed` (engine: advanced per request)
+    const unsigned long long* seed_ptr = nullptr;  // device array [rows] overriding `seed`: one draw stream per slot (engine: per request and per refill)
     const int* forced = nullptr;                   // teacher forcing (tests): see TalkerSampleArgs
 };
 

@@ -29,8 +29,8 @@ struct Engine {
     int* d_codes = nullptr;  // [max_frames][B][16]
     int* d_forced = nullptr; // [max_frames][B][16] teacher-forced ids (q3e_set_forced_codes), allocated on first use
     bool forced_on = false;
-    unsigned long long* d_seed = nullptr;  // draw-stream seed of the current request (device scalar: graph-safe)
-    unsigned long long n_requests = 0;
+    unsigned long long* d_seed = nullptr;  // [max_batch] draw-stream seed of every slot (device array: graph-safe)
+    unsigned long long n_requests = 0, req_seed = 0, n_refills = 0;
     float* d_pad = nullptr;
     // run state
     int B = 0, ignore_eos = 0, cap_frames = 0, frames_run = 0;
@@ -223,10 +223,7 @@ void* q3e_create(const char* weights, int max_batch, int n_ctx, int max_frames) 
     int prio_lo = 0, prio_hi = 0;
     const bool use_prio = !(getenv("Q3_STREAM_PRIO") && atoi(getenv("Q3_STREAM_PRIO")) == 0) &&
                           hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess && prio_lo != prio_hi;
-    std::vector<uint32_t> cu_mask;   // Q3_VOC_CUS: the frame loop takes the CUs the vocoder's stream does not (q3_common.h)
-    const bool partition = cu_partition_mask(true, cu_mask);
     auto mkstream = [&](hipStream_t* st) {
-        if (partition) return hipExtStreamCreateWithCUMask(st, (uint32_t)cu_mask.size(), cu_mask.data()) == hipSuccess;
         return (use_prio ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_hi)
                          : hipStreamCreateWithFlags(st, hipStreamNonBlocking)) == hipSuccess;
     };
@@ -251,8 +248,8 @@ void* q3e_create(const char* weights, int max_batch, int n_ctx, int max_frames) 
     ok = ok && ialloc(&e->d_lastrow, max_batch);
     ok = ok && ialloc(&e->d_codes, (size_t)max_frames * max_batch * 16);
     ok = ok && hipMalloc((void**)&e->d_pad, sizeof(float) * c.hidden) == hipSuccess;
-    ok = ok && hipMalloc((void**)&e->d_seed, sizeof(unsigned long long)) == hipSuccess;
-    ok = ok && hipMemset(e->d_seed, 0, sizeof(unsigned long long)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&e->d_seed, sizeof(unsigned long long) * max_batch) == hipSuccess;
+    ok = ok && hipMemset(e->d_seed, 0, sizeof(unsigned long long) * max_batch) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&e->h_done, sizeof(int) * max_batch, 0) == hipSuccess;
     if (ok) {
         std::vector<int> iota(max_batch);
@@ -442,8 +439,10 @@ int q3e_start(void* ee, int B, const float* prefix, const int32_t* n_rows, const
         unsigned long long z = e->seed + 0x9E3779B97F4A7C15ull * e->n_requests++;
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        const unsigned long long req_seed = e->n_requests == 1 ? e->seed : (z ^ (z >> 31));
-        Q3_HIP(hipMemcpy(e->d_seed, &req_seed, sizeof(req_seed), hipMemcpyHostToDevice), -1);
+        e->req_seed = e->n_requests == 1 ? e->seed : (z ^ (z >> 31));
+        e->n_refills = 0;
+        std::vector<unsigned long long> seeds(B, e->req_seed);   // (the row index separates the slots' draws)
+        Q3_HIP(hipMemcpy(e->d_seed, seeds.data(), sizeof(unsigned long long) * B, hipMemcpyHostToDevice), -1);
     }
     if (e->forced_on) {   // forcing belongs to the batch it was set for
         e->forced_on = false;
@@ -556,7 +555,13 @@ int q3e_get_done(void* ee, int32_t* done, int32_t* frames) {
     Engine* e = (Engine*)ee;
     if (!e || !done || e->B <= 0) return -1;
     Q3_HIP(hipMemcpy(done, e->d_done, sizeof(int) * e->B, hipMemcpyDeviceToHost), -1);
-    if (frames) Q3_HIP(hipMemcpy(frames, e->d_npast, sizeof(int) * e->B, hipMemcpyDeviceToHost), -1);
+    std::vector<int> np(e->B);
+    Q3_HIP(hipMemcpy(np.data(), e->d_npast, sizeof(int) * e->B, hipMemcpyDeviceToHost), -1);
+    // the device raises done[b] on the step AFTER the budget's last frame, a step q3e_run never takes: an utterance
+    // that has emitted its whole budget has ended
+    for (int b = 0; b < e->B; b++)
+        if (np[b] >= e->cap_frames) done[b] = 1;
+    if (frames) memcpy(frames, np.data(), sizeof(int) * e->B);
     return 0;
 }
 
@@ -592,6 +597,14 @@ int q3e_refill(void* ee, int n, const int32_t* slots, const float* prefix, const
         Q3_HIP(hipMemcpyAsync(e->d_ntext + b, n_text + u, sizeof(int), hipMemcpyHostToDevice, e->s), -1);
         Q3_HIP(hipMemcpyAsync(e->d_pos0 + b, n_rows + u, sizeof(int), hipMemcpyHostToDevice, e->s), -1);
         Q3_HIP(hipMemcpyAsync(e->d_posdec + b, n_rows + u, sizeof(int), hipMemcpyHostToDevice, e->s), -1);
+        // a fresh draw stream for the new occupant: the counters (frame, group) restart with the slot, so keeping the
+        // request's seed would replay the previous occupant's uniforms
+        unsigned long long z = e->req_seed + 0xD1B54A32D192ED03ull * ++e->n_refills;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        Q3_HIP(hipMemcpyAsync(e->d_seed + b, &z, sizeof(z), hipMemcpyHostToDevice, e->s), -1);   // (synchronised below: z is a local)
+        Q3_HIP(hipStreamSynchronize(e->s), -1);
     }
     Q3_HIP(hipStreamSynchronize(e->s), -1);
     if (prefill_ids(e, n, ids.data(), prefix, n_rows, e->B)) return -1;

@@ -495,6 +495,15 @@ bool Pack::add_safetensors(const char* path, std::string (*rename)(const std::st
                 j.ok = false;
                 break;
             }
+            // The code predictor's first op (scripts/export_code_predictor_onnx.py:38-41): talker hidden -> predictor
+            // hidden.  Identity -- no tensors -- for the 0.6 B model whose two widths are both 1024
+            // (export_code_predictor_weights.py:51-74 carries none); a checkpoint that DOES hold it is a model this
+            // build has no op for, and dropping the tensor would compute something else silently.
+            if (key.find("small_to_mtp_projection") != std::string::npos) {
+                Q3_LOG("%s: tensor %s: this checkpoint has a talker -> code-predictor projection (small_to_mtp_projection); "
+                       "only the identity form (Qwen3-TTS 0.6B: both widths 1024) is built -- refusing to ignore it", path, key.c_str());
+                return false;
+            }
             const std::string name = rename(key);
             if (!name.empty()) {
                 PackTensor t;

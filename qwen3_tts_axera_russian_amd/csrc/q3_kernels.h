@@ -135,7 +135,7 @@ struct TalkerSampleArgs {
     float temperature = 0.f, top_p = 0.95f;
     int top_k = 50;              // <= 0 or >= V: every entry (the reference skips its argpartition then)
     unsigned long long seed = 0;
-    const unsigned long long* seed_ptr = nullptr;  // device scalar overriding `seed` (advanced per request, graph-safe)
+    const unsigned long long* seed_ptr = nullptr;  // device array [rows] overriding `seed`: one draw stream per slot (per request and per refill, graph-safe)
     // teacher forcing (tests): same layout as `codes`; entries >= 0 replace the decision that is FED BACK
     // (ring of past ids, CP input, feedback sum) while `codes` still records what the device decided
     const int* forced = nullptr;
@@ -166,7 +166,7 @@ struct CpArgmaxArgs {
     float temperature = 0.f;   // <= 1e-6: arg-max
     int top_k = 50;            // <= 0 or >= V: every entry
     unsigned long long seed = 0;
-    const unsigned long long* seed_ptr = nullptr;  // device scalar overriding `seed`
+    const unsigned long long* seed_ptr = nullptr;  // device array [rows] overriding `seed` (one stream per slot)
     const int* forced = nullptr;                   // teacher forcing (tests), see TalkerSampleArgs
 };
 int launch_cp_argmax(hipStream_t s, const CpArgmaxArgs& a);

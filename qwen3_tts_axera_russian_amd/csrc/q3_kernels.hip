@@ -1793,7 +1793,7 @@ __global__ void talker_sample_kernel(TalkerSampleArgs a) {
     }
     if (stochastic) {
         __syncthreads();
-        const float u = uniform01(a.seed_ptr ? *a.seed_ptr : a.seed, (unsigned)r, (unsigned)a.n_frames[r], 0u);
+        const float u = uniform01(a.seed_ptr ? a.seed_ptr[r] : a.seed, (unsigned)r, (unsigned)a.n_frames[r], 0u);
         bidx = block_sample_topk(slg, a.V, a.top_k, a.temperature, a.top_p, u, sv, si, selv, seli);
     } else {
         block_argmax(best, bidx, sv, si);
@@ -1952,7 +1952,7 @@ __global__ void __launch_bounds__(256) cp_argmax_kernel(CpArgmaxArgs a) {
         __syncthreads();
         for (int v = tid; v < a.V; v += 256) slg[v] = nan_as_inf(a.logits[(size_t)r * a.V + v]);
         __syncthreads();
-        const float u = uniform01(a.seed_ptr ? *a.seed_ptr : a.seed, (unsigned)r, (unsigned)nf_r, 1u + (unsigned)a.group);
+        const float u = uniform01(a.seed_ptr ? a.seed_ptr[r] : a.seed, (unsigned)r, (unsigned)nf_r, 1u + (unsigned)a.group);
         bidx = block_sample_topk(slg, a.V, a.top_k, a.temperature, 0.f, u, sv2, si2, selv, seli);
     }
     if (bidx < 0 || bidx >= a.V) bidx = 0;   // every logit -inf: numpy's argmax answers 0; never gather with an invalid winner

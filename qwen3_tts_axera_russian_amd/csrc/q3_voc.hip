@@ -1259,14 +1259,8 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
     Voc* v = new Voc();
     v->chunk = chunk_tokens > 0 ? chunk_tokens : 64;
     v->max_batch = max_batch > 0 ? max_batch : 1;
-    // Q3_VOC_CUS=n: confine the vocoder's stream to n compute units, spread evenly over the XCDs (bit i of
-    // the mask = CU i), so a concurrently running latency-bound frame loop keeps the others to itself.
     bool ok = true;
-    std::vector<uint32_t> mask;
-    if (cu_partition_mask(false, mask)) {
-        ok = hipExtStreamCreateWithCUMask(&v->s, (uint32_t)mask.size(), mask.data()) == hipSuccess;
-        if (!ok) Q3_LOG("hipExtStreamCreateWithCUMask failed");
-    } else {
+    {
         // lowest queue priority: the vocoder is throughput work that runs beside the latency-bound frame
         // loop (highest priority, q3_engine.hip); Q3_STREAM_PRIO=0 creates both at the default priority
         int lo = 0, hi = 0;

@@ -115,10 +115,13 @@ class FrameEngine:
         nxt = B
         self.start(prefixes[:B], n_text[:B], ignore_eos=ignore_eos, max_frames=max_frames)
         while any(o is not None for o in owner):
-            self.run(check_every)
+            ran = self.run(check_every)
             done, per = self.done()
-            fin = [b for b in range(B) if owner[b] is not None and done[b]]
+            # an utterance that used its whole frame budget without an EOS has ended too (q3e_get_done reports it)
+            fin = [b for b in range(B) if owner[b] is not None and (done[b] or per[b] >= max_frames)]
             if not fin:
+                if ran == 0:
+                    raise RuntimeError("generate_queue: the engine ran no frame and no utterance finished")
                 continue
             codes, _ = self.codes()
             for b in fin:

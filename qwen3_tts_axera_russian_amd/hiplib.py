@@ -31,6 +31,10 @@ def load(path: str | None = None):
     if not os.path.exists(p):
         raise RuntimeError(f"{p} not found: build it with `python -m qwen3_tts_axera_russian_amd.build` "
                            "(the HIP library is the only compute path)")
+    # One HIP hardware queue for this process (csrc/q3_common.cpp): a process-wide runtime policy, so the
+    # entry point exports it -- before the first HIP call of the process; a value the user exported wins.
+    if os.environ.get("Q3_KEEP_HW_QUEUES", "0") in ("", "0"):
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
     lib = ctypes.CDLL(p)
     # include/qwen3tts_talker.h
     _sig(lib, "wrapper_backend_init", None, [])

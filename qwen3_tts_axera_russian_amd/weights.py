@@ -304,6 +304,12 @@ def from_hf_checkpoint(model_dir: str, out_path: str, cfg: ModelConfig | None = 
     from safetensors.torch import load_file
     cfg = cfg or ModelConfig()
     w = load_file(os.path.join(model_dir, "model.safetensors"))
+    extra = [k for k in w if "small_to_mtp_projection" in k]
+    if extra:
+        # first op of the code predictor (scripts/export_code_predictor_onnx.py:38-41): identity, without tensors, in the
+        # 0.6 B model; a checkpoint that carries it needs an op this build does not have
+        raise ValueError(f"{model_dir}: {extra[0]} present: only the identity talker -> code-predictor projection "
+                         "(Qwen3-TTS 0.6B) is supported; refusing to ignore it")
     f32 = lambda k: w[k].float().numpy()
     t = {}
     for i in range(cfg.talker_layers):

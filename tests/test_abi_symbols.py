@@ -71,27 +71,41 @@ def test_fails_loudly_without_gpu_or_weights(lib, tmp_path):
         LlamaCppModel(str(tmp_path / "nope.q3w"))
 
 
-def _queues_seen_by_a_fresh_process(preset):
-    """GPU_MAX_HW_QUEUES in the C environment of a fresh process after the library was loaded."""
+def _queues_seen_by_a_fresh_process(preset, keep=False, via_hiplib=False):
+    """(GPU_MAX_HW_QUEUES in the C environment of a fresh process after the library was loaded, its stderr)."""
     import subprocess
     import sys
     env = dict(os.environ)
     env.pop("GPU_MAX_HW_QUEUES", None)
+    env.pop("Q3_KEEP_HW_QUEUES", None)
     if preset is not None:
         env["GPU_MAX_HW_QUEUES"] = preset
-    code = ("import ctypes\n"
-            "from qwen3_tts_axera_russian_amd import build\n"
-            "ctypes.CDLL(build.build())\n"
+    if keep:
+        env["Q3_KEEP_HW_QUEUES"] = "1"
+    load = ("from qwen3_tts_axera_russian_amd import hiplib\nhiplib.load()\n" if via_hiplib else
+            "from qwen3_tts_axera_russian_amd import build\nctypes.CDLL(build.build())\n")
+    code = ("import ctypes\n" + load +
             "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p\n"
-            "print(libc.getenv(b'GPU_MAX_HW_QUEUES').decode())\n")
-    return subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, env=env, text=True).strip().splitlines()[-1]
+            "v = libc.getenv(b'GPU_MAX_HW_QUEUES')\nprint(v.decode() if v else 'unset')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, text=True, capture_output=True, check=True)
+    return r.stdout.strip().splitlines()[-1], r.stderr
 
 
-def test_library_asks_for_one_hardware_queue_unless_the_user_chose():
-    """csrc/q3_common.cpp: a constructor sets GPU_MAX_HW_QUEUES=1 before the HIP runtime reads its flags (DESIGN.md 4,
-    'one hardware queue'); a value the user exported wins."""
-    assert _queues_seen_by_a_fresh_process(None) == "1"
-    assert _queues_seen_by_a_fresh_process("4") == "4"
+def test_one_hardware_queue_is_asked_for_in_the_open():
+    """GPU_MAX_HW_QUEUES=1 ('one hardware queue') is a process-wide HIP policy: the Python entry point
+    exports it itself (silently: it is the host program); a host that dlopens the library directly gets it from the
+    library's constructor, WITH one line on stderr; a value the user exported wins; Q3_KEEP_HW_QUEUES=1 keeps the
+    runtime's default."""
+    v, err = _queues_seen_by_a_fresh_process(None)
+    assert v == "1" and err.count("GPU_MAX_HW_QUEUES=1 set for this process") == 1
+    v, err = _queues_seen_by_a_fresh_process("4")
+    assert v == "4" and "GPU_MAX_HW_QUEUES" not in err
+    v, err = _queues_seen_by_a_fresh_process(None, keep=True)
+    assert v == "unset" and "GPU_MAX_HW_QUEUES" not in err
+    v, err = _queues_seen_by_a_fresh_process(None, via_hiplib=True)
+    assert v == "1" and "GPU_MAX_HW_QUEUES" not in err
+    v, err = _queues_seen_by_a_fresh_process(None, keep=True, via_hiplib=True)
+    assert v == "unset"
 
 
 def test_hot_kernels_do_not_spill_registers():

@@ -349,3 +349,59 @@ def test_generate_queue_keeps_every_slot_busy_and_matches_per_utterance_runs(gpu
     assert sum(st == "exact" for st in stats) >= 3, stats
     assert len({len(g) for g in got}) > 2    # the utterances really had different lengths
     eng.destroy()
+
+
+def test_generate_queue_ends_utterances_at_their_frame_budget(gpu_lib, world):
+    """An utterance that uses its whole frame budget without an EOS has ended (include/qwen3tts_engine.h: done = EOS, or
+    its frame budget): the device raises its done flag only on the step after the budget, a step q3e_run never takes,
+    so q3e_get_done reports the budget itself.  5 utterances, EOS suppressed, through 2 slots with a budget of 6 frames:
+    every one comes back with exactly 6 frames (this loop used to spin forever), through refills, and a queue whose
+    budget is not a multiple of the polling interval ends as well."""
+    path, cfg, tensors, cpu = world
+    rng = np.random.default_rng(75)
+    prefixes = _prefixes(rng, [12, 15, 9, 14, 11])
+    n_text = [30, 30, 30, 30, 30]
+    pad = (0.05 * rng.standard_normal(1024)).astype(np.float32)
+    eng = FrameEngine(path, max_batch=2, n_ctx=64, max_frames=8)
+    eng.set_pad_embed(pad)
+    for cap, every in ((6, 4), (5, 8)):
+        got = eng.generate_queue(prefixes, n_text, cap, ignore_eos=True, check_every=every)
+        assert [len(g) for g in got] == [cap] * 5
+        assert all(((g >= 0) & (g < 2048)).all() for g in got)
+    eng.start(prefixes[:2], n_text[:2], ignore_eos=True, max_frames=6)
+    assert eng.run(6) == 6
+    done, per = eng.done()
+    assert done.all() and list(per) == [6, 6]
+    assert eng.run(4) == 0                       # nothing left of the budget ...
+    assert eng.done()[0].all()                   # ... and the utterances are reported as ended
+    eng.destroy()
+
+
+def test_a_refilled_slot_draws_from_its_own_stream(gpu_lib, world):
+    """Sampling (temperature > 0): the uniform of a decision is a counter-based draw keyed by (slot's seed, row, frame,
+    group).  q3e_refill restarts the frame counter, so the new occupant gets a NEW per-slot seed: given the very same
+    prefix as the previous occupant of its slot it must not reproduce that occupant's codes, while a fresh q3e_start
+    with the same seed reproduces the first occupant exactly (determinism per seed is kept)."""
+    path, cfg, tensors, cpu = world
+    rng = np.random.default_rng(76)
+    prefixes = _prefixes(rng, [12, 14])
+    pad = (0.05 * rng.standard_normal(1024)).astype(np.float32)
+    F = 10
+
+    def first_run():
+        eng = FrameEngine(path, max_batch=2, n_ctx=64, max_frames=F)
+        eng.set_pad_embed(pad)
+        eng.set_sampling(talker_temperature=1.0, talker_top_k=50, talker_top_p=0.95, cp_temperature=1.0, cp_top_k=50, seed=99)
+        eng.start(prefixes, [30, 30], ignore_eos=True, max_frames=F)
+        assert eng.run(F) == F
+        return eng, eng.codes()[0].copy()
+    eng, a = first_run()
+    eng.refill([0], [prefixes[0]], [30])         # the same utterance again, into the slot it just left
+    assert eng.run(F) == F
+    b = eng.codes()[0].copy()
+    eng.destroy()
+    assert not np.array_equal(a[:, 0], b[:, 0]), "the refilled slot replayed its previous occupant's random draws"
+    assert (a[:, 0] != b[:, 0]).mean() > 0.3
+    eng2, a2 = first_run()
+    eng2.destroy()
+    np.testing.assert_array_equal(a2, a)          # same seed, same request index -> same draws

@@ -144,12 +144,23 @@ def test_engine_requests_draw_from_different_streams(gpu_lib, pack):
     assert (outs[0][0] != outs[0][1]).any()                    # but request 2 is not a replay of request 1
 
 
-def test_voc_load_rejects_chunks_the_overlap_walk_cannot_step(gpu_lib, tmp_path):
+def test_chunk_walk_refuses_chunks_the_overlap_walk_cannot_step(gpu_lib, tmp_path):
+    """Any chunk length decodes (the goldens of tests/golden/code2wav_golden.npz are 8-11 frames long); the multi-chunk
+    walk steps by chunk - 16 and bounds its output by n + chunk frames, which needs chunk > 32: voc_synthesize says so
+    for a request longer than such a chunk, and still serves one that fits a single chunk."""
     from qwen3_tts_axera_russian_amd import weights as W
     vp = str(tmp_path / "v.q3w")
     W.write_pack(vp, {"voc_chunk": 64.0}, W.make_synthetic_voc(W.tiny_voc_config(), seed=7))
-    for bad in (1, 16, 32):
-        assert not gpu_lib.voc_load(vp.encode(), bad, 1)
+    for short in (16, 32):
+        hs = gpu_lib.voc_load(vp.encode(), short, 1)
+        assert hs and gpu_lib.voc_chunk_tokens(hs) == short
+        codes = np.random.default_rng(1).integers(0, 2048, size=(short + 5, 16)).astype(np.int64)
+        out = np.empty(gpu_lib.voc_synthesize_max_samples(hs, short + 5), np.float32)
+        ns = np.zeros(1, np.int32)
+        assert gpu_lib.voc_synthesize_f32(hs, codes.ctypes.data_as(hiplib.i64p), short + 5, hiplib.fptr(out), hiplib.iptr(ns)) == -1
+        assert gpu_lib.voc_synthesize_f32(hs, codes.ctypes.data_as(hiplib.i64p), short - 1, hiplib.fptr(out), hiplib.iptr(ns)) == 0
+        assert int(ns[0]) == (short - 1) * 1920
+        gpu_lib.voc_free(hs)
     h = gpu_lib.voc_load(vp.encode(), 48, 1)
     assert h
     n = 100

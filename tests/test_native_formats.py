@@ -165,3 +165,28 @@ def test_safetensors_hf_and_rekeyed_keys(tmp_path):
     tens, meta = inspect(f)
     assert tens["talker.codec_embedding"] == (0, (3072, 8), fnv1a(emb[:3072].numpy().tobytes()))
     assert "talker.layers.0.q_proj" in tens and "talker.norm" in tens and meta["talker_layers"] == 1
+
+
+def test_checkpoint_with_a_talker_to_predictor_projection_is_refused(tmp_path):
+    """The code predictor's first op, `small_to_mtp_projection` (scripts/export_code_predictor_onnx.py:38-41), is the
+    identity -- and has no tensors -- in the 0.6 B model (export_code_predictor_weights.py:51-74 exports none).  A
+    snapshot that carries it is a model this build has no op for: the native loader refuses it instead of dropping the
+    tensor, and so does the Python converter."""
+    torch = pytest.importorskip("torch")
+    from safetensors.torch import save_file
+    from qwen3_tts_axera_russian_amd import weights as W
+    t = {"talker.model.norm.weight": torch.ones(8), "talker.codec_head.weight": torch.zeros(3072, 8),
+         "talker.model.codec_embedding.weight": torch.zeros(3072, 8)}
+    ok, bad = tmp_path / "ok", tmp_path / "bad"
+    ok.mkdir()
+    bad.mkdir()
+    save_file(t, str(ok / "model.safetensors"))
+    tens, _ = inspect(ok)
+    assert tens is not None and "talker.norm" in tens
+    t["talker.code_predictor.small_to_mtp_projection.weight"] = torch.zeros(8, 16)
+    t["talker.code_predictor.small_to_mtp_projection.bias"] = torch.zeros(8)
+    save_file(t, str(bad / "model.safetensors"))
+    tens, _ = inspect(bad)
+    assert tens is None
+    with pytest.raises(ValueError, match="small_to_mtp_projection"):
+        W.from_hf_checkpoint(str(bad), str(tmp_path / "out.q3w"))
