@@ -210,7 +210,55 @@ def run_leg(eng, voc, prefixes, n_text, pad, frames, steps, warmup, sync_all):
     sync_all()
     dt = time.perf_counter() - t0
     pool.shutdown()
+    run_leg.last_codes = eng.codes()[0].copy()      # what the LAST timed step computed (checked outside the timed region)
     return dt, float(np.mean(frame_ms)), float(np.mean(prefill_ms)), float(np.mean(voc.ms)) if voc is not None else 0.0
+
+
+NEAR_TIE = 5e-3     # tests/test_gpu_engine.py: THE tolerance -- oracle top-1/top-2 gap below which two float pipelines may differ
+
+
+def verify_against_fixture(codes, B, F, seed, world, prefixes, n_text, pad):
+    """Result check of the benchmark itself (the reference's client reports RTF for audio it really wrote,
+    tts_client.py:268-271): the codec ids of the last TIMED step against the committed CPU-oracle trajectory of this
+    exact workload (tests/golden/bench_b32_f64.npz, made by tests/golden/make_bench_golden.py) -- a data file, nothing
+    under oracle/ is imported.  Free-running greedy streams of two float pipelines are identical up to a decision whose
+    oracle top-1/top-2 gap is a float near-tie (< NEAR_TIE); anything else fails the benchmark."""
+    import hashlib
+    fx = os.path.join(ROOT, "tests", "golden", "bench_b32_f64.npz")
+    if world != 1 or not os.path.exists(fx):
+        return {"checked": False, "why": "the fixture covers the single-GPU workload (bench.workload(32, 0, 1234))"}
+    g = np.load(fx)
+    ids, margins = g["ids"].astype(np.int32), g["margins"].astype(np.float32)
+    h = hashlib.sha256()
+    for p_ in prefixes:
+        h.update(np.ascontiguousarray(p_).tobytes())
+    h.update(np.asarray(n_text, np.int32).tobytes())
+    h.update(np.ascontiguousarray(pad).tobytes())
+    if (B, F, seed) != (ids.shape[0], ids.shape[1], int(g["seed"])) or h.hexdigest() != bytes(g["inputs_sha"]).decode():
+        return {"checked": False, "why": f"fixture is for batch {ids.shape[0]} x {ids.shape[1]} frames, seed {int(g['seed'])}"}
+    lead, bad, worst = [], [], 0.0
+    for b in range(B):
+        eq = (codes[:F, b, :] == ids[b])
+        if eq.all():
+            lead.append(F)
+            continue
+        f = int(np.argmin(eq.all(axis=1)))
+        gidx = int(np.argmin(eq[f]))
+        gap = float(margins[b, f, gidx])
+        worst = max(worst, gap)
+        lead.append(f)
+        if not gap < NEAR_TIE:
+            bad.append((b, f, gidx, gap))
+    res = {"checked": True, "fixture": "tests/golden/bench_b32_f64.npz (CPU oracle, same weights and prompts)",
+           "utterances": B, "frames": F, "rule": f"identical ids up to a decision whose oracle top-1/top-2 gap < {NEAR_TIE}",
+           "ok": not bad, "utterances_identical_over_all_frames": int(sum(x == F for x in lead)),
+           "identical_leading_frames": {"min": int(min(lead)), "median": int(np.median(lead)), "total": int(sum(lead)),
+                                        "of": B * F},
+           "largest_oracle_gap_at_a_divergence": round(worst, 6)}
+    if bad:
+        print(f"[bench] RESULT CHECK FAILED: codes diverge from the oracle at decisions that are no near-ties: {bad[:5]}",
+              file=sys.stderr, flush=True)
+    return res
 
 
 def longform_leg(lib, path, voc_path, prefix, n_text, pad, frames):
@@ -452,6 +500,7 @@ def main():
         # (fp32-grade against float64) is reported beside it as an option
         lib.voc_set_exact_fp32(1)
     dt, frame_ms_step, prefill_ms, voc_ms = run_leg(eng, voc, prefixes, n_text, pad, F, a.steps, a.warmup, sync_all)
+    verified = verify_against_fixture(run_leg.last_codes, B, F, a.seed, world, prefixes, n_text, pad)
     # the frame graph alone on the chip (inside a step the previous step's vocoder chunk runs beside it and the two
     # split the machine: the step time is their sum either way, the kernel-quality figure is this one)
     eng.start(prefixes, n_text, ignore_eos=True, max_frames=F)
@@ -480,6 +529,7 @@ def main():
         "rtf": round((dt / a.steps) / (F * FRAME_SEC), 5),
         "rtf_aggregate": round((dt / a.steps) / (world * B * F * FRAME_SEC), 6),
         "prefill_ms": round(prefill_ms, 3), "vocoder_ms_per_step": round(voc_ms_step, 3),
+        "verified": verified,
         "roofline": None,
         "roofline_step": {"kernel": "frame-step hipGraph (talker 28L + 15 code-predictor passes + heads, 553 nodes)",
                           "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -547,6 +597,8 @@ def main():
                                      for k, v in table["kinds"].items()}
         print(json.dumps(out), flush=True)
     R.close()
+    if verified.get("checked") and not verified.get("ok"):
+        sys.exit(3)       # a fast step whose codes differ from the reference's is not a result
 
 
 if __name__ == "__main__":

@@ -283,14 +283,16 @@ __global__ void __launch_bounds__(NW * 64)
 
     asm volatile("" ::"v"(acc[0][0][0]));  // (diagnostic stamp below must not float above the MFMAs)
     Q3_PH(2);  // MFMAs done (weights landed)
-    // ---- 4. partial tiles -> LDS.  D layout: col = lane&15, row = 4*(lane>>4) + reg. ----
+    // ---- 4. partial tiles -> LDS.  D layout: col = lane&15, row = 4*(lane>>4) + reg.  (A layout with the four
+    // accumulator registers of a lane adjacent -- one ds_write_b128 per tile instead of four scalar stores -- was
+    // measured in round 3: 2.420 against 2.410 ms per frame at 32 rows, no gain.) ----
+#define RED(w_, row_, col_) red[((w_) * MR + (row_)) * NBP + (col_)]
 #pragma unroll
     for (int mt = 0; mt < MT16; mt++)
 #pragma unroll
         for (int nb = 0; nb < NB16; nb++)
 #pragma unroll
-            for (int r = 0; r < 4; r++)
-                red[(w * MR + mt * 16 + 4 * q + r) * NBP + nb * 16 + c] = acc[mt][nb][r];
+            for (int r = 0; r < 4; r++) RED(w, mt * 16 + 4 * q + r, nb * 16 + c) = acc[mt][nb][r];
     __syncthreads();
     Q3_PH(3);  // partials in LDS, barrier passed
 
@@ -303,7 +305,7 @@ __global__ void __launch_bounds__(NW * 64)
                 const int mr = o / NB, n = o % NB;
                 float v = 0.f;
 #pragma unroll
-                for (int ww = 0; ww < NW; ww++) v += red[(ww * MR + mr) * NBP + n];
+                for (int ww = 0; ww < NW; ww++) v += RED(ww, mr, n);
                 const int m = m0 + mr;
                 const int ng = tile0 * 16 + n;
                 const bool ok = m < a.M;
@@ -334,8 +336,8 @@ __global__ void __launch_bounds__(NW * 64)
                 float g = 0.f, u = 0.f;
 #pragma unroll
                 for (int ww = 0; ww < NW; ww++) {
-                    g += red[(ww * MR + mr) * NBP + (2 * ii) * 16 + cc];
-                    u += red[(ww * MR + mr) * NBP + (2 * ii + 1) * 16 + cc];
+                    g += RED(ww, mr, (2 * ii) * 16 + cc);
+                    u += RED(ww, mr, (2 * ii + 1) * 16 + cc);
                 }
                 const int m = m0 + mr;
                 if (PRO == PRO_NORM) {
@@ -349,6 +351,7 @@ __global__ void __launch_bounds__(NW * 64)
             }
         }
     }
+#undef RED
 }
 
 template <int NB16, int MT16, int KBW, int NW, int PRO, int EPI, bool NT>
@@ -738,6 +741,105 @@ int set_linear_tuning(int K, int mt16, int kbw) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// linear_narrow_kernel<KBW, NW, NT>: the N = 1024 projections (o: K = 2048, down: K = 3072; fp16 input, residual
+// epilogue) at <= 64 rows, as their own kernel.  The body of a weight-streaming launch is bound by the bytes each CU
+// pulls through its L1 (~77 GB/s per CU), and N = 1024 has only 64 column tiles: with 16-row groups
+// a 32-row pass runs 128 workgroups of (16 rows + 16 weight rows) x K x 2 B = 128 / 192 KB each on half the chip.
+// Here a workgroup owns 8 rows x 16 columns: 256 workgroups at 32 rows, (8 + 16) x K x 2 B = 96 / 144 KB each, one
+// per CU -- and at <= 8 rows (one utterance) the 64 workgroups fetch 8 activation rows instead of 16.  The MFMA is
+// still 16 x 16 x 32: lanes of the other 8 rows load nothing (exec-masked, zeros) and their accumulator rows are
+// dropped.  Everything else is linear_kernel's EPI_RESID path: every load issued up front, split-K over the NW waves,
+// fixed-order LDS reduction, h += acc, 16-column sum-of-squares partials and the consumer's pre-scaled xh.
+// Workgroups of one column tile have equal blockIdx.x % 8 (the grid's x extent is 64): one XCD under round-robin
+// placement, so the tile's weights come from HBM once and from that L2 for the other row groups.
+// ---------------------------------------------------------------------------
+template <int KBW, int NW, bool NT>
+__global__ void __launch_bounds__(NW * 64)
+    linear_narrow_kernel(const half_t* __restrict__ p_wp, const half_t* __restrict__ p_x16, float* __restrict__ p_h,
+                         const float* __restrict__ p_gamma, float* __restrict__ p_ssq_out, half_t* __restrict__ p_xh_out,
+                         int p_M, int p_m_begin, int tl_node) {
+    constexpr int KB = NW * KBW, K = KB * 32, N = 1024, RG = 8;
+#ifdef Q3_TIMELINE
+    LinArgs a;
+    a.tl_node = tl_node;
+#endif
+    Q3_TL(10 + PRO_F16 * 4 + EPI_RESID);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int q = lane >> 4, c = lane & 15;
+    const int tile0 = blockIdx.x;
+    const int m0 = p_m_begin + blockIdx.y * RG;          // first row of this group (p_m_begin % 16 == 0)
+    const int blk0 = m0 & ~15, half = (m0 >> 3) & 1;     // its 16-row fragment block, and which half of it
+    // partial tiles: [wave][4-row group of the 8 rows][column][4 rows] -- a lane's four accumulator registers are
+    // four consecutive floats, one ds_write_b128 (as four scalar stores at a row stride of 20 floats the ROCm 7.2
+    // compiler merged two of them into a ds_write2_b32 with a wrong first offset -- 5 instead of 20 dwords -- when
+    // the accumulators lived in AGPRs: seen in the ISA and in the results of the KBW = 16, NW = 4 instantiation)
+    __shared__ __attribute__((aligned(16))) float red[NW * 2 * 16 * 4];
+    // ---- every global load of the kernel, up front (epilogue operands first: vmcnt retires in order) ----
+    const int mr = tid >> 4, n = tid & 15;               // epilogue mapping: threads 0..127 = 8 rows x 16 columns
+    const int m = m0 + mr, ng = tile0 * 16 + n;
+    const bool epi_thread = tid < RG * 16, ok = epi_thread && m < p_M;
+    float hold = 0.f, gnext = 0.f;
+    if (ok) hold = p_h[frag_idx(m, ng, N)];
+    if (epi_thread && p_gamma) gnext = p_gamma[ng];
+    h8 wf[KBW], af[KBW];
+#pragma unroll
+    for (int kbi = 0; kbi < KBW; kbi++) {
+        const h8* p = (const h8*)(p_wp + (((size_t)tile0 * KB + (size_t)w * KBW + kbi) * 64 + lane) * 8);
+        wf[kbi] = NT ? __builtin_nontemporal_load(p) : *p;
+    }
+    // Lane c holds row blk0 + c of the 16-row block; the lanes of the block's other half fetch nothing.  Their A rows
+    // may hold anything (a row of D depends on its own row of A only, and their accumulator rows are dropped), so
+    // ONE exec-masked region covers all KBW loads and nothing is merged afterwards.
+    const bool live = (c >> 3) == half;
+    if (live) {
+#pragma unroll
+        for (int kbi = 0; kbi < KBW; kbi++)
+            af[kbi] = *(const h8*)(p_x16 + frag_idx(blk0 + c, (w * KBW + kbi) * 32 + q * 8, K));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    Q3_PH(0);  // all loads issued
+    f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kbi = 0; kbi < KBW; kbi++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kbi], wf[kbi], acc, 0, 0, 0);
+    Q3_PH(2);  // MFMAs done (weights landed)
+    // D layout: col = lane & 15, row = 4 * (lane >> 4) + reg: this group's rows 8 half .. 8 half + 7 sit in q = 2 half, 2 half + 1
+    if ((q >> 1) == half) *(f4*)(red + ((w * 2 + (q & 1)) * 16 + c) * 4) = acc;
+    __syncthreads();
+    Q3_PH(3);
+    if (epi_thread) {      // wave-uniform (128 threads = waves 0 and 1)
+        float v = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ww++) v += red[((ww * 2 + (mr >> 2)) * 16 + n) * 4 + (mr & 3)];
+        const float hn = ok ? hold + v : 0.f;
+        if (ok) p_h[frag_idx(m, ng, N)] = hn;
+        if (ok && p_xh_out) p_xh_out[frag_idx(m, ng, N)] = pre_scaled(hn, gnext);
+        float s = hn * hn;
+        s += __shfl_xor(s, 8, 16);
+        s += __shfl_xor(s, 4, 16);
+        s += __shfl_xor(s, 2, 16);
+        s += __shfl_xor(s, 1, 16);
+        if (ok && n == 0) p_ssq_out[(size_t)m * (N / 16) + tile0] = s;
+    }
+}
+
+static int g_narrow8 = getenv("Q3_LINEAR_NARROW8") ? atoi(getenv("Q3_LINEAR_NARROW8")) : 1;
+int set_linear_narrow8(int on) { g_narrow8 = on; return 0; }
+
+template <int KBW, int NW>
+static int launch_linear_narrow_t(hipStream_t s, const LinArgs& a) {
+    const int groups = (a.M - a.m_begin + 7) / 8;
+    const int node = tl_next_node();
+    if (a.nt)
+        hipLaunchKernelGGL((linear_narrow_kernel<KBW, NW, true>), dim3(64, groups), dim3(NW * 64), 0, s, a.wp, a.x16, a.h_out, a.gamma,
+                           a.ssq_out, a.xh_out, a.M, a.m_begin, node);
+    else
+        hipLaunchKernelGGL((linear_narrow_kernel<KBW, NW, false>), dim3(64, groups), dim3(NW * 64), 0, s, a.wp, a.x16, a.h_out, a.gamma,
+                           a.ssq_out, a.xh_out, a.M, a.m_begin, node);
+    Q3_HIP(hipGetLastError(), -1);
+    return 0;
+}
+
 #define Q3_LIN_CASE(NB16_, MT16_, KBW_, NW_, PRO_, EPI_)                                   \
     if (nb16 == NB16_ && mt16 == MT16_ && kbw == KBW_ && nw == NW_ && pro == PRO_ && epi == EPI_) \
         return launch_linear_t<NB16_, MT16_, KBW_, NW_, PRO_, EPI_>(s, a);
@@ -756,6 +858,12 @@ int launch_linear(hipStream_t s, const LinArgs& a, int pro, int epi) {
     if (ki < 0 || a.N % 32) {
         Q3_LOG("launch_linear: unsupported shape N=%d K=%d", a.N, K);
         return -1;
+    }
+    if (g_narrow8 && pro == PRO_F16 && epi == EPI_RESID && a.N == 1024 && a.m_begin % 16 == 0 && a.ssq_out) {
+        // o / down: 8-row groups, one workgroup per CU at 32 rows (linear_narrow_kernel)
+        // (waves per workgroup probed on MI355X: 4 / 8 / 16 for K = 2048 and 8 / 16 / 4 for K = 3072 all within 0.3 %)
+        if (K == 2048) return launch_linear_narrow_t<16, 4>(s, a);
+        if (K == 3072) return launch_linear_narrow_t<12, 8>(s, a);
     }
     int mt16 = rows <= 16 ? 1 : rows <= 32 ? 2 : 4;
     // narrow outputs (o/down, N = 1024) have only N/16 = 64 column tiles: split the rows over two
@@ -917,7 +1025,7 @@ int launch_gather_embed(hipStream_t s, const float* table, int V, int H, const i
 // with an online softmax per group, groups are merged by shuffles inside a wave and through LDS
 // across waves: two barriers in all, no n_ctx-sized LDS.
 // ---------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, int APRE>
 __global__ void __launch_bounds__(1024) attn_kernel(AttnArgs a) {
     constexpr int D = 128;
     Q3_FETCH_ARGS("s"(a.qkv), "s"(a.ld), "s"(a.row0), "s"(a.q_norm), "s"(a.k_norm), "s"(a.eps), "s"(a.rope_cos), "s"(a.rope_sin),
@@ -963,7 +1071,9 @@ __global__ void __launch_bounds__(1024) attn_kernel(AttnArgs a) {
     }
     float qpre = 0.f;
     if (MODE == ATTN_ATTEND && tid < 2 * D) qpre = row[(size_t)(2 * g) * D + tid];
-    constexpr int APRE = 4;
+    // APRE cached rows per 16-lane group are requested up front: 4 x 64 groups (1024 threads, one utterance) or
+    // 8 x 16 groups (256 threads, a batch of 32) = the first 256 / 128 positions without a second memory round trip
+    // (a batch-32 step at positions 65-113 took the dependent in-loop loads with APRE = 4: -0.8 % per frame with 8)
     h8 kpre[APRE], vpre[APRE];
     if (MODE != ATTN_PREP) {
 #pragma unroll
@@ -1523,8 +1633,11 @@ int launch_attn(hipStream_t s, const AttnArgs& a, int mode) {
     dim3 grid(a.R, a.n_kv);
 #define Q3_ATTN(MODE_)                                                                                   \
     {                                                                                                    \
-        hipLaunchKernelGGL((attn_kernel<MODE_>), grid, dim3(mode == ATTN_PREP ? 256 : threads),          \
-                           mode == ATTN_PREP ? 0 : lds, s, a2);                                          \
+        if (threads <= 256)                                                                              \
+            hipLaunchKernelGGL((attn_kernel<MODE_, 8>), grid, dim3(256), mode == ATTN_PREP ? 0 : lds, s, a2); \
+        else                                                                                             \
+            hipLaunchKernelGGL((attn_kernel<MODE_, 4>), grid, dim3(mode == ATTN_PREP ? 256 : threads),   \
+                               mode == ATTN_PREP ? 0 : lds, s, a2);                                      \
     }
     if (mode == ATTN_FUSED) Q3_ATTN(ATTN_FUSED)
     else if (mode == ATTN_PREP) Q3_ATTN(ATTN_PREP)

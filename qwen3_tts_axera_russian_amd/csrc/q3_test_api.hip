@@ -9,6 +9,7 @@ using namespace q3;
 namespace q3 {
 int set_linear_tuning(int K, int mt16, int kbw);
 int set_linear_split_rows(int on);
+int set_linear_narrow8(int on);
 int set_linear_wide_tiles(int on);
 int set_attn_short(int on);
 int set_gemm_min_rows(int n);
@@ -30,6 +31,7 @@ extern "C" {
 
 int q3t_set_linear_tuning(int K, int mt16, int kbw) { return set_linear_tuning(K, mt16, kbw); }
 int q3t_set_linear_split_rows(int on) { return set_linear_split_rows(on); }
+int q3t_set_linear_narrow8(int on) { return set_linear_narrow8(on); }   // 0: o / down through linear_kernel (round 2)
 int q3t_set_linear_wide_tiles(int on) { return set_linear_wide_tiles(on); }
 int q3t_set_attn_short(int on) { return set_attn_short(on); }
 // rows >= n take the tiled GEMM (gemm_kernel) instead of the weight-streaming kernel; default 65

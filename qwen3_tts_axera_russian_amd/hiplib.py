@@ -123,6 +123,7 @@ def load_test():
                                     f32p, f32p, u16p, c_int])
     _sig(lib, "q3t_talker_sample", c_int, [f32p, c_int, i32p, c_int, c_int, c_int])
     _sig(lib, "q3t_set_linear_split_rows", c_int, [c_int])
+    _sig(lib, "q3t_set_linear_narrow8", c_int, [c_int])
     _sig(lib, "q3t_set_linear_wide_tiles", c_int, [c_int])
     _sig(lib, "q3t_set_attn_short", c_int, [c_int])
     _sig(lib, "q3t_set_gemm_min_rows", c_int, [c_int])

@@ -63,7 +63,7 @@ def main():
             flops = 2.0 * p1 * p2 * p3 * L * B          # k taps per input column
             byt = 4.0 * (p1 * L + p2 * L * p4) * B
             name += f" {p1}->{p2} k{p3} s{p4}"
-            L *= p4
+            L = (L - 1) * p4 + p3 - row[6] - row[7]     # kept outputs after the table's trims
             C = p2
         else:
             byt = 8.0 * C * L * B

@@ -405,3 +405,62 @@ def test_a_refilled_slot_draws_from_its_own_stream(gpu_lib, world):
     eng2, a2 = first_run()
     eng2.destroy()
     np.testing.assert_array_equal(a2, a)          # same seed, same request index -> same draws
+
+
+def _bench_fixture():
+    import os
+    import bench
+    from tests.golden.make_bench_golden import inputs_sha
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_b32_f64.npz"))
+    prefixes, n_text, pad = bench.workload(32, 0, int(g["seed"]))
+    assert inputs_sha(prefixes, n_text, pad) == bytes(g["inputs_sha"]).decode(), "bench.workload changed: regenerate the fixture"
+    return g["ids"].astype(np.int32), g["margins"].astype(np.float32), prefixes, n_text, pad
+
+
+def test_the_benchmarked_regime_every_decision_of_64_frames_graded(gpu_lib):
+    """The regime bench.py times -- BASELINE configs[2]: bench.workload(32, 0, 1234), 64 frames (KV 14...113), EOS
+    suppressed, 28 + 5 layers -- against the committed oracle trajectory tests/golden/bench_b32_f64.npz
+    (tests/golden/make_bench_golden.py: oracle/pipeline.py on the same synthetic weights).  Teacher-forced with the
+    oracle's ids, ALL 32 x 64 x 16 = 32 768 greedy decisions are graded under the one tolerance NEAR_TIE; then the same
+    batch free-running: every utterance is identical to the oracle up to a decision whose oracle gap is a near-tie
+    (asserted per utterance by _compare), and the identical prefixes are long enough to mean something (asserted)."""
+    ids, margins, prefixes, n_text, pad = _bench_fixture()
+    B, F = 32, 64
+    path, cfg, _ = synthetic_pack(28, 5)
+    ref_frames = [[list(map(int, ids[b, f])) for f in range(F)] for b in range(B)]
+    mg = [[list(map(float, margins[b, f])) for f in range(F)] for b in range(B)]
+    forced = np.ascontiguousarray(np.transpose(ids, (1, 0, 2)))           # [F][B][16]
+    eng = FrameEngine(path, max_batch=B, n_ctx=max(p.shape[0] for p in prefixes) + F + 8, max_frames=F)
+    eng.set_pad_embed(pad)
+    eng.start(prefixes, n_text, ignore_eos=True, max_frames=F)
+    eng.set_forced_codes(forced)
+    assert eng.run(F) == F
+    dev, per = eng.codes()
+    n, same, flips = _grade_teacher_forced(dev, ref_frames, mg)
+    worst = max((m for *_, m in flips), default=0.0)
+    by_frame = np.zeros(F, int)
+    for _, f, _, _ in flips:
+        by_frame[f] += 1
+    print(f"bench regime, teacher-forced: {same}/{n} decisions identical, {len(flips)} differ (largest oracle gap among them "
+          f"{worst:.2e}); flips in frames 0-15 / 16-31 / 32-47 / 48-63: {[int(by_frame[i:i + 16].sum()) for i in range(0, F, 16)]}")
+    assert n == B * F * 16
+    assert all(m < NEAR_TIE for *_, m in flips), [x for x in flips if x[3] >= NEAR_TIE][:5]
+    assert len(flips) <= 0.02 * n
+    # free-running: what the timed steps really compute
+    eng.start(prefixes, n_text, ignore_eos=True, max_frames=F)
+    assert eng.run(F) == F
+    free, per = eng.codes()
+    assert (per == F).all()
+    stats = _compare(free, per, ref_frames, [m + [[np.inf] * 16] for m in mg])     # asserts: a divergence only at a near-tie
+    same_frames = []
+    for b in range(B):
+        eq = (free[:F, b, :] == ids[b]).all(axis=1)
+        same_frames.append(int(F if eq.all() else np.argmin(eq)))
+    n_exact = sum(st == "exact" for st in stats)
+    print(f"bench regime, free-running: {n_exact} of {B} utterances identical over all {F} frames; identical leading frames per "
+          f"utterance: min {min(same_frames)}, median {int(np.median(same_frames))}, total {sum(same_frames)} of {B * F}")
+    # near-ties are 2.9 % of this trajectory's decisions (954 of 32 768): an utterance meets one every ~2 frames, and the
+    # device takes the other side at roughly one in ten of them; the floor below is half of what was measured on MI355X
+    assert sum(same_frames) >= B * 4, same_frames
+    assert n_exact == sum(1 for x in same_frames if x == F)
+    eng.destroy()
