@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 latency leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-longform", action="store_true", help="skip the long-form latency leg (configs[4])")
+    ap.add_argument("--no-ragged", action="store_true", help="skip the natural-length leg (EOS on, continuous batching, batched vocoder)")
     ap.add_argument("--longform-frames", type=int, default=768, help="frames of the long-form leg (768 = 61.4 s of audio)")
     ap.add_argument("--no-timeline", action="store_true",
                     help="skip the in-graph timeline child process (use under rocprofv3: the profiler follows the child, "
@@ -296,6 +297,77 @@ def longform_leg(lib, path, voc_path, prefix, n_text, pad, frames):
                                "(prefill + frame loop + overlap-crossfade chunk walk, exact-fp32 vocoder)",
                    "frames": frames, "audio_s": round(audio, 2), "wall_s": round(wall, 4), "rtf": round(wall / audio, 5),
                    "first_audio_ms": round(t_first * 1e3, 2), "frame_loop_ms_per_frame": round(eng.last_run_ms / (frames - 64), 4)}
+    lib.voc_free(h)
+    eng.destroy()
+    return res
+
+
+def ragged_leg(lib, path, voc_path, B, seed, rounds=3, max_frames=256):
+    """BASELINE configs[2] as written: mixed prompts at their NATURAL lengths -- EOS bookkeeping on (the adaptive EOS boost
+    and the forced EOS of llamacpp_talker_server.py:167-189 end an utterance after ~3 x n_text frames), `rounds` x the 32
+    prompts queued through B slots by continuous batching (q3e_refill keeps every slot busy), and the streaming
+    overlap-crossfade vocoder at batch: finished utterances are handed to a worker that runs voc_synthesize_batch (the
+    chunk walk of vocoder_server.py:84-117 for all of them in one call, int16 out).  Wall time covers prefills, refills,
+    the frame loop and every vocoder call; one untimed pass first."""
+    from concurrent.futures import ThreadPoolExecutor
+    from qwen3_tts_axera_russian_amd import hiplib
+    from qwen3_tts_axera_russian_amd.engine import FrameEngine
+    total = rounds * len(PROMPT_TOKENS)
+    n_text = [PROMPT_TOKENS[i % len(PROMPT_TOKENS)] for i in range(total)]
+    order = sorted(range(total), key=lambda i: (-n_text[i], i))            # longest expected first (deal()'s rule)
+    prefixes = [(0.03 * np.random.default_rng(seed + 7919 * i).standard_normal((n_text[i] + 9, 1024))).astype(np.float32)
+                for i in order]
+    n_text = [n_text[i] for i in order]
+    pad = (0.03 * np.random.default_rng(seed).standard_normal(1024)).astype(np.float32)
+    eng = FrameEngine(path, max_batch=B, n_ctx=max(p.shape[0] for p in prefixes) + max_frames + 8, max_frames=max_frames)
+    eng.set_pad_embed(pad)
+    lib.voc_set_exact_fp32(1)
+    h = lib.voc_load(voc_path.encode(), 64, B)
+    if not h:
+        raise SystemExit("bench.py: voc_load failed (ragged leg)")
+    pool = ThreadPoolExecutor(max_workers=1)
+    res = None
+    for timed in (False, True):
+        done_codes, futures, voc_ms, chunks, samples = [], [], [], [0], [0]
+
+        def vocode(batch):
+            n = np.array([len(c) for c in batch], np.int32)
+            cat = np.ascontiguousarray(np.concatenate(batch, axis=0), np.int64)
+            cap = int(lib.voc_synthesize_batch_max_samples(h, hiplib.iptr(n), len(n)))
+            out = np.empty(cap, np.int16)
+            off = np.zeros(len(n) + 1, np.int64)
+            assert lib.voc_synthesize_batch(h, cat.ctypes.data_as(hiplib.i64p), hiplib.iptr(n), len(n), out.ctypes.data_as(hiplib.i16p),
+                                            cap, off.ctypes.data_as(hiplib.i64p)) == 0
+            voc_ms.append(float(lib.voc_last_batch_ms(h)))
+            chunks[0] += int(lib.voc_last_batch_chunks(h))
+            samples[0] += int(off[-1])
+
+        def on_done(i, codes):
+            if len(codes) == 0:                      # an utterance whose first decision was EOS: nothing to vocode
+                return
+            done_codes.append(codes)
+            if len(done_codes) >= B // 2:            # stream: hand what has finished to the vocoder while the loop goes on
+                futures.append(pool.submit(vocode, list(done_codes)))
+                done_codes.clear()
+        t0 = time.perf_counter()
+        got = eng.generate_queue(prefixes, n_text, max_frames, ignore_eos=False, check_every=8, on_done=on_done)
+        t_loop = time.perf_counter() - t0
+        if done_codes:
+            futures.append(pool.submit(vocode, list(done_codes)))
+        for f in futures:
+            f.result()
+        wall = time.perf_counter() - t0
+        if timed:
+            frames = [len(g) for g in got]
+            audio = samples[0] / 24000.0
+            res = {"workload": f"configs[2] at natural lengths: {total} utterances ({rounds} x the 32 mixed prompts), EOS rule on, "
+                               f"{B} slots kept busy by continuous batching, batched overlap-crossfade vocoder (exact fp32)",
+                   "utterances": total, "frames_total": int(sum(frames)), "frames_min_median_max": [int(min(frames)), int(np.median(frames)),
+                                                                                                   int(max(frames))],
+                   "wall_s": round(wall, 4), "frame_loop_wall_s": round(t_loop, 4), "value": round(sum(frames) / wall, 1),
+                   "unit": "codec_frames/s", "audio_s": round(audio, 2), "rtf_aggregate": round(wall / audio, 6),
+                   "vocoder_calls": len(voc_ms), "vocoder_chunks": chunks[0], "vocoder_gpu_ms_total": round(float(sum(voc_ms)), 2)}
+    pool.shutdown()
     lib.voc_free(h)
     eng.destroy()
     return res
@@ -586,6 +658,8 @@ def main():
     if rank == 0 and world == 1 and not a.no_longform and not a.no_vocoder:
         out["longform"] = longform_leg(lib, path, make_voc_pack(a.cache, a.seed, rank, barrier), prefixes[0], n_text[0], pad,
                                        a.longform_frames)
+    if rank == 0 and world == 1 and not a.no_ragged and not a.no_vocoder:
+        out["ragged"] = ragged_leg(lib, path, make_voc_pack(a.cache, a.seed, rank, barrier), B, a.seed)
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(path, cfg, prefixes[0], n_text[0], pad, a.cpu_frames,
                                            None if a.no_vocoder else make_voc_pack(a.cache, a.seed, rank, barrier))

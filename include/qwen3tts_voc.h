@@ -52,6 +52,21 @@ int voc_synthesize(void* v, const int64_t* codes, int n_tokens, int16_t* out, in
 int voc_synthesize_f32(void* v, const int64_t* codes, int n_tokens, float* out, int32_t* n_samples);
 int voc_synthesize_max_samples(void* v, int n_tokens);
 
+/* The same for U utterances in one call (BASELINE configs[2]: "streaming overlap-crossfade vocoder" at batch): codes =
+ * the utterances' frames concatenated ([sum n_tokens][16]); the chunks of ALL utterances are decoded max_batch at a time
+ * and every utterance's chunk walk -- 64-frame chunks stepping by 48, the 16-frame linear cross-fade, the appended short
+ * tail chunk (vocoder_server.py:84-117) -- is assembled on the device, bit-identical to voc_synthesize[_f32] per
+ * utterance.  out holds voc_synthesize_batch_max_samples() samples (out_capacity of them are the caller's);
+ * utterance u's samples are out[offsets[u] .. offsets[u+1]) (offsets has U + 1 entries).  0 ok / <0 error. */
+int voc_synthesize_batch(void* v, const int64_t* codes, const int32_t* n_tokens, int U, int16_t* out, int64_t out_capacity,
+                         int64_t* offsets);
+int voc_synthesize_batch_f32(void* v, const int64_t* codes, const int32_t* n_tokens, int U, float* out, int64_t out_capacity,
+                             int64_t* offsets);
+int64_t voc_synthesize_batch_max_samples(void* v, const int32_t* n_tokens, int U);
+/* GPU milliseconds and decoded chunks of the last voc_synthesize_batch* call */
+float voc_last_batch_ms(void* v);
+int voc_last_batch_chunks(void* v);
+
 /* Arithmetic of the convolutions.  Default (0): split precision -- every f32 operand (weights once at load,
  * activations in the producing kernel's epilogue) is carried as two fp16 terms (22 mantissa bits) and each
  * product costs three fp16 MFMAs with f32 accumulation.  1: the exact-f32 MFMA (v_mfma_f32_32x32x2_f32)

@@ -53,7 +53,7 @@ class BatchSynthesisServer:
         self.eng.set_sampling(temperature, top_k, 0.95, cp_temperature, top_k, seed)
         self.n_ctx = n_ctx
         self._lib = hiplib.load()
-        self.voc = self._lib.voc_load(str(vocoder_path).encode(), 64, 1)
+        self.voc = self._lib.voc_load(str(vocoder_path).encode(), 64, min(max_batch, 32))
         if not self.voc:
             raise RuntimeError(f"voc_load failed: {vocoder_path}")
         self._running = True
@@ -96,20 +96,23 @@ class BatchSynthesisServer:
             self.eng.run(max_tokens)
             codes, per = self.eng.codes()
             per_utt = [codes[:int(per[b]), b, :] for b in range(B)]
-        out = []
-        for b in range(B):
-            c = np.ascontiguousarray(per_utt[b], dtype=np.int32)
-            n = c.shape[0]
-            pcm = np.zeros(0, np.int16)
-            if n > 0:
-                c64 = np.ascontiguousarray(c, dtype=np.int64)
-                buf = np.empty(self._lib.voc_synthesize_max_samples(self.voc, n), np.int16)
-                ns = np.zeros(1, np.int32)
-                if self._lib.voc_synthesize(self.voc, c64.ctypes.data_as(hiplib.i64p), n, buf.ctypes.data_as(hiplib.i16p),
-                                            hiplib.iptr(ns)) != 0:
-                    raise RuntimeError("voc_synthesize failed")
-                pcm = buf[:ns[0]].copy()
-            out.append((c, pcm))
+        # the vocoder: every utterance's chunk walk in ONE batched call (voc_synthesize_batch: chunks of all utterances
+        # decoded together, overlap-crossfade assembled on the device; per utterance = VocoderServer.synthesize + int16)
+        cs = [np.ascontiguousarray(per_utt[b], dtype=np.int32) for b in range(B)]
+        live = [b for b in range(B) if cs[b].shape[0] > 0]
+        pcm = {b: np.zeros(0, np.int16) for b in range(B)}
+        if live:
+            n = np.array([cs[b].shape[0] for b in live], np.int32)
+            cat = np.ascontiguousarray(np.concatenate([cs[b] for b in live], axis=0), dtype=np.int64)
+            cap = int(self._lib.voc_synthesize_batch_max_samples(self.voc, hiplib.iptr(n), len(n)))
+            buf = np.empty(cap, np.int16)
+            off = np.zeros(len(n) + 1, np.int64)
+            if self._lib.voc_synthesize_batch(self.voc, cat.ctypes.data_as(hiplib.i64p), hiplib.iptr(n), len(n),
+                                              buf.ctypes.data_as(hiplib.i16p), cap, off.ctypes.data_as(hiplib.i64p)) != 0:
+                raise RuntimeError("voc_synthesize_batch failed")
+            for k, b in enumerate(live):
+                pcm[b] = buf[off[k]:off[k + 1]].copy()
+        out = [(cs[b], pcm[b]) for b in range(B)]
         return out
 
     def serve(self):

@@ -1151,6 +1151,53 @@ __global__ void __launch_bounds__(256) embmean_kernel(const int64_t* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------
+// Batched chunk walk (voc_synthesize_batch): the reference assembles an utterance from its 64-frame chunks on the host
+// (vocoder_server.py:84-117: first chunk kept, every next one either cross-faded over 16 frames with the tail of what
+// is there, or -- shorter than the overlap -- appended).  Here the chunks of MANY utterances are decoded max_batch at a
+// time and placed by two launches per batch: every chunk copies its samples behind the blended head to its position,
+// then every blended chunk folds its head into the 30 720 samples already there (written by its predecessor's copy,
+// this batch or an earlier one).  A chunk shorter than twice the overlap has no successor (the walk steps by
+// chunk - 16 frames), so no sample is blended twice and the two-pass order reproduces the sequential result bit for bit:
+// float32 products and one float32 add, never fused (numpy: result[-OV:] * fade_out + chunk[:OV] * fade_in), the fade
+// np.linspace(1, 0, OV, dtype=float32) evaluated in double exactly as numpy does.
+// ---------------------------------------------------------------------------
+struct ChunkPlace {
+    int row;            // row of the decode batch's output
+    int len;            // samples of the chunk after the reference's slice (min(frames * 1920, chunk_samples))
+    int head;           // 0: plain append; OV: the first OV samples are cross-faded into what is already there
+    long long dst;      // sample index in the batch output buffer where the chunk's first sample lands
+};
+
+__global__ void __launch_bounds__(256) voc_place_copy_kernel(const float* __restrict__ dec, int pitch, const ChunkPlace* __restrict__ pl,
+                                                             float* __restrict__ out) {
+    const ChunkPlace p = pl[blockIdx.y];
+    const float* src = dec + (size_t)p.row * pitch;
+    for (int i = p.head + blockIdx.x * 256 + threadIdx.x; i < p.len; i += gridDim.x * 256) out[p.dst + i] = src[i];
+}
+
+__global__ void __launch_bounds__(256) voc_place_blend_kernel(const float* __restrict__ dec, int pitch, const ChunkPlace* __restrict__ pl,
+                                                              float* __restrict__ out, int OV) {
+    const ChunkPlace p = pl[blockIdx.y];
+    if (p.head == 0) return;
+    const float* src = dec + (size_t)p.row * pitch;
+    const double step = -1.0 / (double)(OV - 1);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < OV; i += gridDim.x * 256) {
+        const float fo = (i == OV - 1) ? 0.0f : (float)(1.0 + (double)i * step);
+        const float fi = __fsub_rn(1.0f, fo);
+        out[p.dst + i] = __fadd_rn(__fmul_rn(out[p.dst + i], fo), __fmul_rn(src[i], fi));
+    }
+}
+
+// np.clip(audio * 32767, -32768, 32767).astype(np.int16) (vocoder_server.py:175): float32 product, truncation toward zero
+__global__ void __launch_bounds__(256) voc_to_int16_kernel(const float* __restrict__ x, int16_t* __restrict__ y, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = __fmul_rn(x[i], 32767.0f);
+    v = v < -32768.0f ? -32768.0f : (v > 32767.0f ? 32767.0f : v);
+    y[i] = (int16_t)v;
+}
+
 struct VocOp {
     int op = 0, cin = 0, cout = 0, k = 0, p0 = 0, flags = 0, nq = 0, cb = 0;
     float *w = nullptr, *bias = nullptr, *alpha = nullptr, *inv_beta = nullptr;  // device
@@ -1188,6 +1235,13 @@ struct Voc {
     float last_ms = 0.f;
     double flops_per_chunk = 0.0;
     std::vector<float> h_chunk;
+    // batched chunk walk: assembled waveforms of a request (grown on demand) and the per-batch placement table
+    float* d_wave = nullptr;
+    int16_t* d_wave16 = nullptr;
+    size_t wave_cap = 0, wave16_cap = 0;
+    ChunkPlace* d_place = nullptr;   // [max_batch]
+    float batch_ms = 0.f;            // GPU time of the last voc_synthesize_batch*
+    int batch_chunks = 0;            // chunks it decoded
 };
 
 static float* voc_up(Voc* v, const PackTensor* t) {
@@ -1225,6 +1279,9 @@ static void voc_destroy(Voc* v) {
     for (_Float16* b : v->plane)
         if (b) hipFree(b);
     if (v->d_codes) hipFree(v->d_codes);
+    if (v->d_wave) hipFree(v->d_wave);
+    if (v->d_wave16) hipFree(v->d_wave16);
+    if (v->d_place) hipFree(v->d_place);
     if (v->d_ovf) hipFree(v->d_ovf);
     if (v->e0) hipEventDestroy(v->e0);
     if (v->e1) hipEventDestroy(v->e1);
@@ -1563,6 +1620,7 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
         for (int i = 0; i < 4 && ok; i++) ok = hipMalloc((void**)&v->plane[i], v->buf_elems * 2) == hipSuccess;
         ok = ok && hipMalloc((void**)&v->d_codes, sizeof(int64_t) * 16 * v->chunk * v->max_batch) == hipSuccess;
         ok = ok && hipMalloc((void**)&v->d_ovf, 16) == hipSuccess && hipMemset(v->d_ovf, 0, 16) == hipSuccess;
+        ok = ok && hipMalloc((void**)&v->d_place, sizeof(ChunkPlace) * v->max_batch) == hipSuccess;
     }
     if (!ok) {
         Q3_LOG("voc_load failed");
@@ -1978,6 +2036,146 @@ int voc_synthesize_f32(void* vv, const int64_t* codes, int n, float* out, int32_
     *n_samples = (int32_t)have;
     return 0;
 }
+
+// ---- batched VocoderServer.synthesize ----
+namespace {
+struct WalkChunk { int utt, start, len; size_t cl; int head; long long dst; };
+
+// the reference's walk for one utterance of n frames whose output starts at sample `base` -> its chunks, returns its length
+size_t plan_walk(const Voc* v, int u, int n, long long base, std::vector<WalkChunk>& out) {
+    const int CH = v->chunk, SPT = v->upsample;
+    const size_t CS = (size_t)v->chunk_samples, OV = (size_t)16 * SPT;
+    auto sliced = [&](int len) -> size_t { return (size_t)len * SPT < CS ? (size_t)len * SPT : CS; };
+    if (n <= CH) {
+        out.push_back({u, 0, n, sliced(n), 0, base});
+        return sliced(n);
+    }
+    size_t have = 0;
+    for (int start = 0; start < n; start += CH - 16) {
+        const int len = (start + CH <= n) ? CH : n - start;
+        const size_t cl = sliced(len);
+        if (start == 0) {
+            out.push_back({u, start, len, cl, 0, base});
+            have = cl;
+        } else if (have >= OV && cl >= OV) {
+            out.push_back({u, start, len, cl, (int)OV, base + (long long)(have - OV)});
+            have += cl - OV;
+        } else {
+            out.push_back({u, start, len, cl, 0, base + (long long)have});
+            have += cl;
+        }
+    }
+    return have;
+}
+
+int synth_batch(Voc* v, const int64_t* codes, const int32_t* n_tokens, int U, int64_t* offsets, bool want16, void* out, int64_t cap) {
+    if (!v || !codes || !n_tokens || !offsets || !out || U <= 0) return -1;
+    const int CH = v->chunk;
+    std::vector<WalkChunk> walk;
+    std::vector<size_t> code_off(U);
+    long long total = 0;
+    size_t coff = 0;
+    for (int u = 0; u < U; u++) {
+        if (n_tokens[u] <= 0) {
+            Q3_LOG("voc_synthesize_batch: utterance %d has %d frames", u, n_tokens[u]);
+            return -1;
+        }
+        if (n_tokens[u] > CH && CH <= 32) {
+            Q3_LOG("voc_synthesize_batch: chunk_tokens=%d is too short for the 16-frame overlap walk (need > 32)", CH);
+            return -1;
+        }
+        offsets[u] = total;
+        code_off[u] = coff;
+        coff += (size_t)n_tokens[u] * 16;
+        total += (long long)plan_walk(v, u, n_tokens[u], total, walk);
+    }
+    offsets[U] = total;
+    if (total > cap) {
+        Q3_LOG("voc_synthesize_batch: %lld samples do not fit the caller's buffer of %lld", total, (long long)cap);
+        return -1;
+    }
+    if ((size_t)total > v->wave_cap) {
+        if (v->d_wave) hipFree(v->d_wave);
+        v->d_wave = nullptr;
+        v->wave_cap = 0;
+        Q3_HIP(hipMalloc((void**)&v->d_wave, sizeof(float) * (size_t)total), -1);
+        v->wave_cap = (size_t)total;
+    }
+    const int pitch = (int)pitch4(v->chunk_samples), OV = 16 * v->upsample;
+    std::vector<int64_t> padded((size_t)v->max_batch * CH * 16);
+    std::vector<ChunkPlace> place(v->max_batch);
+    bool redo_exact = false;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        Q3_HIP(hipEventRecord(v->e0, v->s), -1);
+        for (size_t c0 = 0; c0 < walk.size(); c0 += v->max_batch) {
+            const int B = (int)((walk.size() - c0 < (size_t)v->max_batch) ? walk.size() - c0 : v->max_batch);
+            std::fill(padded.begin(), padded.begin() + (size_t)B * CH * 16, 0);
+            for (int b = 0; b < B; b++) {
+                const WalkChunk& w = walk[c0 + b];
+                memcpy(padded.data() + (size_t)b * CH * 16, codes + code_off[w.utt] + (size_t)w.start * 16, sizeof(int64_t) * 16 * w.len);
+                place[b] = {b, (int)w.cl, w.head, w.dst};
+            }
+            Q3_HIP(hipMemcpyAsync(v->d_codes, padded.data(), sizeof(int64_t) * 16 * (size_t)CH * B, hipMemcpyHostToDevice, v->s), -1);
+            Q3_HIP(hipMemcpyAsync(v->d_place, place.data(), sizeof(ChunkPlace) * B, hipMemcpyHostToDevice, v->s), -1);
+            float* res = nullptr;
+            if (voc_run(v, B, &res, -1, nullptr, nullptr, nullptr, redo_exact)) return -1;
+            hipLaunchKernelGGL(voc_place_copy_kernel, dim3(64, B), dim3(256), 0, v->s, res, pitch, v->d_place, v->d_wave);
+            hipLaunchKernelGGL(voc_place_blend_kernel, dim3(32, B), dim3(256), 0, v->s, res, pitch, v->d_place, v->d_wave, OV);
+            Q3_HIP(hipGetLastError(), -1);
+            Q3_HIP(hipStreamSynchronize(v->s), -1);   // the staging vectors are reused by the next batch
+        }
+        Q3_HIP(hipEventRecord(v->e1, v->s), -1);
+        int ovf = 0;
+        if (g_voc_split && !redo_exact) Q3_HIP(hipMemcpyAsync(&ovf, v->d_ovf, sizeof(int), hipMemcpyDeviceToHost, v->s), -1);
+        Q3_HIP(hipStreamSynchronize(v->s), -1);
+        if (!ovf) break;
+        // an activation beyond the fp16 range: the whole request is redone on the exact-fp32 path (voc_decode's rule)
+        if (!v->warned_ovf) Q3_LOG("vocoder: activation outside the fp16 range, decoding this request with the exact-fp32 path");
+        v->warned_ovf = true;
+        Q3_HIP(hipMemsetAsync(v->d_ovf, 0, sizeof(int), v->s), -1);
+        redo_exact = true;
+    }
+    hipEventElapsedTime(&v->batch_ms, v->e0, v->e1);
+    v->batch_chunks = (int)walk.size();
+    if (!want16) {
+        Q3_HIP(hipMemcpyAsync(out, v->d_wave, sizeof(float) * (size_t)total, hipMemcpyDeviceToHost, v->s), -1);
+    } else {
+        if ((size_t)total > v->wave16_cap) {
+            if (v->d_wave16) hipFree(v->d_wave16);
+            v->d_wave16 = nullptr;
+            v->wave16_cap = 0;
+            Q3_HIP(hipMalloc((void**)&v->d_wave16, sizeof(int16_t) * (size_t)total), -1);
+            v->wave16_cap = (size_t)total;
+        }
+        hipLaunchKernelGGL(voc_to_int16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, v->s, v->d_wave, v->d_wave16, total);
+        Q3_HIP(hipGetLastError(), -1);
+        Q3_HIP(hipMemcpyAsync(out, v->d_wave16, sizeof(int16_t) * (size_t)total, hipMemcpyDeviceToHost, v->s), -1);
+    }
+    Q3_HIP(hipStreamSynchronize(v->s), -1);
+    return 0;
+}
+}  // namespace
+
+int64_t voc_synthesize_batch_max_samples(void* vv, const int32_t* n_tokens, int U) {
+    Voc* v = (Voc*)vv;
+    if (!v || !n_tokens || U <= 0) return 0;
+    int64_t t = 0;
+    for (int u = 0; u < U; u++) t += n_tokens[u] > 0 ? (int64_t)voc_synthesize_max_samples(v, n_tokens[u]) : 0;
+    return t;
+}
+
+int voc_synthesize_batch_f32(void* vv, const int64_t* codes, const int32_t* n_tokens, int U, float* out, int64_t out_capacity,
+                             int64_t* offsets) {
+    return synth_batch((Voc*)vv, codes, n_tokens, U, offsets, false, out, out_capacity);
+}
+
+int voc_synthesize_batch(void* vv, const int64_t* codes, const int32_t* n_tokens, int U, int16_t* out, int64_t out_capacity,
+                         int64_t* offsets) {
+    return synth_batch((Voc*)vv, codes, n_tokens, U, offsets, true, out, out_capacity);
+}
+
+float voc_last_batch_ms(void* vv) { return vv ? ((Voc*)vv)->batch_ms : -1.f; }
+int voc_last_batch_chunks(void* vv) { return vv ? ((Voc*)vv)->batch_chunks : 0; }
 
 int voc_synthesize(void* vv, const int64_t* codes, int n, int16_t* out, int32_t* n_samples) {
     Voc* v = (Voc*)vv;

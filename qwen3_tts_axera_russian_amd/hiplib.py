@@ -93,6 +93,12 @@ def load(path: str | None = None):
     _sig(lib, "voc_set_fused_units", c_int, [c_int])
     _sig(lib, "voc_last_decode_ms", c_float, [c_void_p])
     _sig(lib, "voc_decode_flops", ctypes.c_double, [c_void_p, c_int])
+    i64p_ = ctypes.POINTER(ctypes.c_int64)
+    _sig(lib, "voc_synthesize_batch", c_int, [c_void_p, i64p, i32p, c_int, i16p, ctypes.c_int64, i64p_])
+    _sig(lib, "voc_synthesize_batch_f32", c_int, [c_void_p, i64p, i32p, c_int, f32p, ctypes.c_int64, i64p_])
+    _sig(lib, "voc_synthesize_batch_max_samples", ctypes.c_int64, [c_void_p, i32p, c_int])
+    _sig(lib, "voc_last_batch_ms", c_float, [c_void_p])
+    _sig(lib, "voc_last_batch_chunks", c_int, [c_void_p])
     # include/qwen3tts_text.h
     _sig(lib, "tfe_load", c_void_p, [c_char_p, c_char_p, c_int])
     _sig(lib, "tfe_free", None, [c_void_p])

@@ -24,10 +24,10 @@ SAMPLES_PER_TOKEN = 1920
 
 
 class VocoderServer:
-    def __init__(self, model_path, socket_path="/tmp/qwen3_voc.sock", max_tokens=64, install_signal_handlers=True):
+    def __init__(self, model_path, socket_path="/tmp/qwen3_voc.sock", max_tokens=64, install_signal_handlers=True, max_batch=1):
         self.socket_path = socket_path
         self._lib = hiplib.load()
-        self.h = self._lib.voc_load(str(model_path).encode(), max_tokens, 1)
+        self.h = self._lib.voc_load(str(model_path).encode(), max_tokens, max_batch)
         if not self.h:
             raise RuntimeError(f"Failed to load vocoder: {model_path}")
         self.max_tokens = self._lib.voc_chunk_tokens(self.h)
@@ -66,6 +66,21 @@ class VocoderServer:
                                     hiplib.iptr(ns)):
             raise RuntimeError("voc_synthesize failed")
         return out[:ns[0]]
+
+    def synthesize_batch(self, codes_list, int16=True):
+        """U utterances in one call (include/qwen3tts_voc.h: voc_synthesize_batch): codes_list[u] is [n_u, 16]; the chunks
+        of all utterances are decoded together and each utterance's overlap-crossfade walk (synthesize above, per
+        utterance) is assembled on the device.  -> list of int16 (or float32) arrays."""
+        n = np.array([len(c) for c in codes_list], np.int32)
+        cat = np.ascontiguousarray(np.concatenate([np.asarray(c)[:, :16] for c in codes_list], axis=0), np.int64)
+        cap = int(self._lib.voc_synthesize_batch_max_samples(self.h, hiplib.iptr(n), len(n)))
+        out = np.empty(cap, np.int16 if int16 else np.float32)
+        off = np.zeros(len(n) + 1, np.int64)
+        fn = self._lib.voc_synthesize_batch if int16 else self._lib.voc_synthesize_batch_f32
+        ptr = out.ctypes.data_as(hiplib.i16p) if int16 else hiplib.fptr(out)
+        if fn(self.h, cat.ctypes.data_as(hiplib.i64p), hiplib.iptr(n), len(n), ptr, cap, off.ctypes.data_as(hiplib.i64p)) != 0:
+            raise RuntimeError("voc_synthesize_batch failed")
+        return [out[off[u]:off[u + 1]].copy() for u in range(len(n))]
 
     def serve(self):
         if os.path.exists(self.socket_path):

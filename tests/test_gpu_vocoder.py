@@ -368,3 +368,51 @@ def test_split_arithmetic_falls_back_when_out_of_fp16_range(gpu_lib, tiny_voc, t
             np.testing.assert_array_equal(outs[0], outs[1])        # the whole call was redone exactly
         else:
             assert np.abs(outs[0] - outs[1]).max() < 2e-4          # that op exact, the others split
+
+
+@pytest.mark.parametrize("trim", ["both", "right"])
+def test_batched_chunk_walk_is_bit_identical_to_the_per_utterance_walk(gpu_lib, tmp_path, trim):
+    """voc_synthesize_batch (BASELINE configs[2]: the overlap-crossfade vocoder at batch): utterances of ragged lengths --
+    single chunk, exactly one chunk, the first blend, the appended short tail (n = 97 -> a 1-frame chunk; 150 -> 6 frames),
+    a chunk shorter than the overlap -- with max_batch 5, so decode batches mix chunks of different utterances and split
+    utterances across batches (the blend then folds into samples an EARLIER batch placed).  Per utterance the result is
+    bit-identical to the restatement pinned to the reference's VocoderServer.synthesize (oracle/frontend.voc_synthesize
+    around single-chunk decodes), as float32 and as int16, in both arithmetic modes and for both trims of the table."""
+    vc = W.tiny_voc_config()
+    vc.convt_trim = trim
+    path = str(tmp_path / f"voc_{trim}.q3w")
+    W.write_pack(path, {"voc_chunk": 64.0}, W.make_synthetic_voc(vc, seed=7))
+    rng = np.random.default_rng(41)
+    lens = [1, 10, 64, 65, 97, 150, 33, 112, 80]
+    utts = [rng.integers(0, 2048, size=(n, 16)).astype(np.int64) for n in lens]
+    nn = np.array(lens, np.int32)
+    cat = np.ascontiguousarray(np.concatenate(utts, axis=0))
+    for exact in (1, 0):
+        gpu_lib.voc_set_exact_fp32(exact)
+        v = Voc(gpu_lib, path, max_batch=5)
+        cap = int(gpu_lib.voc_synthesize_batch_max_samples(v.h, hiplib.iptr(nn), len(nn)))
+        assert cap == sum(gpu_lib.voc_synthesize_max_samples(v.h, n) for n in lens)
+        off = np.zeros(len(lens) + 1, np.int64)
+        out = np.empty(cap, np.float32)
+        assert gpu_lib.voc_synthesize_batch_f32(v.h, cat.ctypes.data_as(hiplib.i64p), hiplib.iptr(nn), len(nn), hiplib.fptr(out), cap,
+                                                off.ctypes.data_as(hiplib.i64p)) == 0
+        out16 = np.empty(cap, np.int16)
+        off16 = np.zeros(len(lens) + 1, np.int64)
+        assert gpu_lib.voc_synthesize_batch(v.h, cat.ctypes.data_as(hiplib.i64p), hiplib.iptr(nn), len(nn),
+                                            out16.ctypes.data_as(hiplib.i16p), cap, off16.ctypes.data_as(hiplib.i64p)) == 0
+        np.testing.assert_array_equal(off, off16)
+        assert gpu_lib.voc_last_batch_chunks(v.h) == sum(1 if n <= 64 else len(range(0, n, 48)) for n in lens)
+        for u, codes in enumerate(utts):
+            want = fe.voc_synthesize(codes, lambda padded: v.decode(padded)[0], 64)
+            got = out[off[u]:off[u + 1]]
+            assert len(got) == len(want), (u, lens[u])
+            np.testing.assert_array_equal(got, want)
+            np.testing.assert_array_equal(out16[off[u]:off[u + 1]], fe.to_int16(want))
+            np.testing.assert_array_equal(got, v.synth_f32(codes))             # == the single-utterance entry point
+        # too small a caller buffer is refused, nothing is written past it
+        small = np.full(int(off[-1]) - 1, 7.0, np.float32)
+        assert gpu_lib.voc_synthesize_batch_f32(v.h, cat.ctypes.data_as(hiplib.i64p), hiplib.iptr(nn), len(nn), hiplib.fptr(small),
+                                                len(small), off.ctypes.data_as(hiplib.i64p)) == -1
+        assert (small == 7.0).all()
+        v.close()
+    gpu_lib.voc_set_exact_fp32(0)
