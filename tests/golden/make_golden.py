@@ -83,6 +83,48 @@ for i, n in enumerate([1, 5, 20]):
     G[f"prefix_{i}_ids"] = ids.astype(np.int64)
     G[f"prefix_{i}_out"] = srv._build_prefix(list(ids))
 
+# The same two functions at the widths the DEVICE text path is built for (text dim 2048 -> 2048 -> hidden 1024:
+# include/qwen3tts_text.h runs fc1 / fc2 on the talker's MFMA GEMM kernels, whose K is 1024 / 2048 / 3072), so
+# tests/test_gpu_text.py can compare tfe_build_prefix with the reference's own output directly.  A 151 936 x 2048
+# f32 table is 1.2 GB; the reference only ever indexes it (`self.text_embedding[token_ids]`), so it gets an object
+# whose row(id) is row id % 640 of a 640-row table -- the reference's code and constants are untouched, the
+# special ids it looks up (151644, 77091, 198, 151671-3) land on rows 604, 291, 198, 631-633.
+WV = 640
+
+
+class ModTable:
+    def __init__(self, small):
+        self.small = small
+
+    def __getitem__(self, ids):
+        return self.small[np.asarray(ids) % self.small.shape[0]]
+
+
+def wide_tables(seed):
+    r = np.random.default_rng(seed)
+    return dict(text_embedding=(0.05 * r.standard_normal((WV, 2048))).astype(np.float32),
+                proj_fc1_w=(0.02 * r.standard_normal((2048, 2048))).astype(np.float32),
+                proj_fc1_b=(0.02 * r.standard_normal(2048)).astype(np.float32),
+                proj_fc2_w=(0.02 * r.standard_normal((1024, 2048))).astype(np.float32),
+                proj_fc2_b=(0.02 * r.standard_normal(1024)).astype(np.float32),
+                codec_embedding=(0.05 * r.standard_normal((CV, 1024))).astype(np.float32))
+
+
+wsrv = object.__new__(ts.Qwen3TTSTalkerServer)
+for k, v in wide_tables(12).items():
+    setattr(wsrv, k, v)
+wsrv.text_embedding = ModTable(wsrv.text_embedding)
+wsp = wsrv._embed_text(np.array([ts.TTS_PAD_TOKEN_ID, ts.TTS_BOS_TOKEN_ID, ts.TTS_EOS_TOKEN_ID]))
+wsrv.tts_pad_embed, wsrv.tts_bos_embed, wsrv.tts_eos_embed = wsp[0], wsp[1], wsp[2]
+G["wprefix_seed"] = np.array(12)
+wid_rng = np.random.default_rng(6)
+for i, n in enumerate([2, 9]):
+    ids = wid_rng.integers(0, 600, size=n)
+    G[f"wprefix_{i}_ids"] = ids.astype(np.int64)
+    out = wsrv._build_prefix(list(ids))
+    assert out.shape == (n + 9, 1024) and out.dtype == np.float32
+    G[f"wprefix_{i}_out"] = out
+
 # sampling: temperature 0 (greedy limit) across the EOS-boost / force / repetition regimes
 cases = []
 srng = np.random.default_rng(21)

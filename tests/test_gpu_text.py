@@ -93,3 +93,46 @@ def test_loads_the_reference_embeddings_directory(gpu_lib, pack, tmp_path):
     np.testing.assert_array_equal(a.build_prefix(ids), b.build_prefix(ids))
     a.destroy()
     b.destroy()
+
+
+def _wide_tables(seed):
+    """tests/golden/make_golden.py::wide_tables, regenerated from its seed"""
+    r = np.random.default_rng(seed)
+    return dict(text_embedding=(0.05 * r.standard_normal((640, 2048))).astype(np.float32),
+                fc1_w=(0.02 * r.standard_normal((2048, 2048))).astype(np.float32),
+                fc1_b=(0.02 * r.standard_normal(2048)).astype(np.float32),
+                fc2_w=(0.02 * r.standard_normal((1024, 2048))).astype(np.float32),
+                fc2_b=(0.02 * r.standard_normal(1024)).astype(np.float32),
+                codec_embedding=(0.05 * r.standard_normal((3072, 1024))).astype(np.float32))
+
+
+def test_device_prefix_against_the_references_own_output(gpu_lib, tmp_path):
+    """tfe_build_prefix compared DIRECTLY with what the reference's `_build_prefix` returned
+    (tests/golden/frontend_golden.npz: wprefix_*, llamacpp_talker_server.py:115-161 run by tests/golden/make_golden.py at
+    the device path's widths: text dim 2048 -> 2048 -> hidden 1024).  The golden's text table is a 640-row table read at
+    id % 640 (the 151 936-row one would be 1.2 GB); the device gets the same 640 rows and the special ids' residues.
+    Tolerance as above: fp16 table / weights / SiLU output with f32 accumulation against f32 numpy, <= 4e-3 of the
+    largest element (measured ~1e-3); rows whose text part is shared are identical where the reference's are."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frontend_golden.npz"))
+    t = _wide_tables(int(g["wprefix_seed"]))
+    cfg = W.ModelConfig(talker_layers=2, cp_layers=2, text_vocab=640, tts_pad=151671 % 640, tts_bos=151672 % 640,
+                        tts_eos=151673 % 640, im_start=151644 % 640, assistant=77091 % 640, newline=198 % 640)
+    path = str(tmp_path / "wide_text.q3w")
+    W.write_pack(path, cfg.meta(), {"text.embedding": t["text_embedding"], "text.fc1.weight": t["fc1_w"], "text.fc1.bias": t["fc1_b"],
+                                    "text.fc2.weight": t["fc2_w"], "text.fc2.bias": t["fc2_b"],
+                                    "talker.codec_embedding": t["codec_embedding"]})
+    dev = fe.DeviceTextFrontEnd(cfg, path, max_tokens=64)
+    host = fe.TextFrontEnd(cfg, t["text_embedding"], t["fc1_w"], t["fc1_b"], t["fc2_w"], t["fc2_b"], t["codec_embedding"])
+    for i in range(2):
+        ids = [int(x) for x in g[f"wprefix_{i}_ids"]]
+        want = g[f"wprefix_{i}_out"]
+        np.testing.assert_array_equal(host.build_prefix(ids), want)        # the host front-end: bit for bit
+        got = dev.build_prefix(ids)
+        assert got.shape == want.shape
+        e = _rel(got, want)
+        print(f"device prefix vs the reference's output, {len(ids)} text tokens: max rel err {e:.2e}")
+        assert e <= TOL, (i, e)
+        # structure the tolerance cannot hide: rows 3..5 differ from each other by codec rows only, exactly
+        codec = t["codec_embedding"]
+        np.testing.assert_allclose(got[4] - got[3], codec[cfg.codec_think_bos] - codec[cfg.codec_nothink], rtol=0, atol=2e-7)
+    dev.destroy()

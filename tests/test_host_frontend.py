@@ -27,6 +27,24 @@ def test_prefix_matches_reference(golden, tt):
     assert front.build_prefix([]).shape == (9, tt["codec_embedding"].shape[1])   # empty text: 9 rows
 
 
+def test_prefix_matches_reference_at_the_real_widths(golden):
+    """The wprefix_* goldens (reference `_build_prefix` at text dim 2048 -> hidden 1024 over a 640-row table read at
+    id % 640): the host front-end reproduces them bit for bit with the special ids' residues."""
+    r = np.random.default_rng(int(golden["wprefix_seed"]))
+    emb = (0.05 * r.standard_normal((640, 2048))).astype(np.float32)
+    fc1_w = (0.02 * r.standard_normal((2048, 2048))).astype(np.float32)
+    fc1_b = (0.02 * r.standard_normal(2048)).astype(np.float32)
+    fc2_w = (0.02 * r.standard_normal((1024, 2048))).astype(np.float32)
+    fc2_b = (0.02 * r.standard_normal(1024)).astype(np.float32)
+    codec = (0.05 * r.standard_normal((3072, 1024))).astype(np.float32)
+    cfg = ModelConfig(text_vocab=640, tts_pad=151671 % 640, tts_bos=151672 % 640, tts_eos=151673 % 640,
+                      im_start=151644 % 640, assistant=77091 % 640, newline=198 % 640)
+    front = fe.TextFrontEnd(cfg, emb, fc1_w, fc1_b, fc2_w, fc2_b, codec)
+    for i in range(2):
+        ids = [int(x) for x in golden[f"wprefix_{i}_ids"]]
+        np.testing.assert_array_equal(front.build_prefix(ids), golden[f"wprefix_{i}_out"])
+
+
 def test_sampler_matches_reference(golden, tt):
     s = fe.TalkerSampler(temperature=0.0)
     for ci in range(int(golden["sample_n"])):
