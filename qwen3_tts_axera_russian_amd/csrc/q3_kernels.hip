@@ -104,6 +104,14 @@ __device__ __forceinline__ half_t sat_half(float x) {
 // keeping |h * gamma| up to 1e6 inside fp16 -- and the consumer multiplies its f32 accumulators by
 // inv_rms(row) * NORM_POST.  The GEMM reads 2 bytes per activation instead of 4 and has no prologue to wait for.
 constexpr float NORM_PRE = 0.0625f, NORM_POST = 16.0f;
+// Stores of the decode kernels' outputs (a few hundred KB per launch, read by the NEXT launch on other XCDs): plain.
+// -DQ3_NT_OUT makes them non-temporal (written through instead of left dirty for the end-of-kernel write-back) --
+// measured in round 3 on MI355X: 2.41 -> 2.49 ms per frame at 32 rows, 2.14 -> 2.20 at one; rejected, kept as a probe.
+#ifdef Q3_NT_OUT
+#define Q3_OUT_STORE(v_, p_) __builtin_nontemporal_store((v_), (p_))
+#else
+#define Q3_OUT_STORE(v_, p_) (*(p_) = (v_))
+#endif
 __device__ __forceinline__ half_t pre_scaled(float h, float g) { return sat_half((h * g) * NORM_PRE); }
 
 // Activations that feed a GEMM (residual stream h, attention output, SwiGLU output) live in MFMA
@@ -311,17 +319,17 @@ __global__ void __launch_bounds__(NW * 64)
                 const bool ok = m < a.M;
                 if (PRO == PRO_NORM) v *= inv_s[mr];
                 if (EPI == EPI_STORE) {
-                    if (ok) a.y[(size_t)m * a.ldy + ng] = v;
+                    if (ok) Q3_OUT_STORE(v, &a.y[(size_t)m * a.ldy + ng]);
                 } else {
                     const float hn = ok ? hold[i] + v : 0.f;
-                    if (ok) a.h_out[frag_idx(m, ng, a.N)] = hn;
-                    if (ok && a.xh_out) a.xh_out[frag_idx(m, ng, a.N)] = pre_scaled(hn, gnext[i]);
+                    if (ok) Q3_OUT_STORE(hn, &a.h_out[frag_idx(m, ng, a.N)]);
+                    if (ok && a.xh_out) Q3_OUT_STORE(pre_scaled(hn, gnext[i]), &a.xh_out[frag_idx(m, ng, a.N)]);
                     float s = hn * hn;
                     s += __shfl_xor(s, 8, 16);
                     s += __shfl_xor(s, 4, 16);
                     s += __shfl_xor(s, 2, 16);
                     s += __shfl_xor(s, 1, 16);
-                    if (ok && (n & 15) == 0) a.ssq_out[(size_t)m * (a.N / 16) + (ng >> 4)] = s;
+                    if (ok && (n & 15) == 0) Q3_OUT_STORE(s, &a.ssq_out[(size_t)m * (a.N / 16) + (ng >> 4)]);
                 }
             }
         }
@@ -346,7 +354,7 @@ __global__ void __launch_bounds__(NW * 64)
                 }
                 if (m < a.M) {
                     const float sg = __fdividef(g, 1.0f + __expf(-g));   // hardware exp/rcp: ~1e-6 relative, far below the fp16 rounding that follows
-                    a.act[frag_idx(m, (tile0 / NB16) * NH + j, a.N / 2)] = sat_half(sg * u);
+                    Q3_OUT_STORE(sat_half(sg * u), &a.act[frag_idx(m, (tile0 / NB16) * NH + j, a.N / 2)]);
                 }
             }
         }
@@ -812,14 +820,14 @@ __global__ void __launch_bounds__(NW * 64)
 #pragma unroll
         for (int ww = 0; ww < NW; ww++) v += red[((ww * 2 + (mr >> 2)) * 16 + n) * 4 + (mr & 3)];
         const float hn = ok ? hold + v : 0.f;
-        if (ok) p_h[frag_idx(m, ng, N)] = hn;
-        if (ok && p_xh_out) p_xh_out[frag_idx(m, ng, N)] = pre_scaled(hn, gnext);
+        if (ok) Q3_OUT_STORE(hn, &p_h[frag_idx(m, ng, N)]);
+        if (ok && p_xh_out) Q3_OUT_STORE(pre_scaled(hn, gnext), &p_xh_out[frag_idx(m, ng, N)]);
         float s = hn * hn;
         s += __shfl_xor(s, 8, 16);
         s += __shfl_xor(s, 4, 16);
         s += __shfl_xor(s, 2, 16);
         s += __shfl_xor(s, 1, 16);
-        if (ok && n == 0) p_ssq_out[(size_t)m * (N / 16) + tile0] = s;
+        if (ok && n == 0) Q3_OUT_STORE(s, &p_ssq_out[(size_t)m * (N / 16) + tile0]);
     }
 }
 

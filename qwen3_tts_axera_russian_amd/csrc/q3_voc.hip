@@ -63,7 +63,7 @@ constexpr int VTN = 128;   // output columns per workgroup (4 waves x 32)
 // Staging goes global -> LDS directly; ~4 workgroups per CU hide its latency (a register-staged software
 // pipeline was tried: 199-256 VGPRs, one workgroup per SIMD, 1.6x slower at 32 chunks).
 template <int MT, int KT, int KC, bool CT = false>   // CT: transposed conv (stride > 1, no residual), stores go through an LDS slab
-__global__ void __launch_bounds__(256, MT >= 4 ? 3 : (MT == 3 ? 3 : 4)) conv_kernel(ConvArgs a) {
+__global__ void __launch_bounds__(256, (KC >= 32 && MT >= 3) ? 2 : (MT >= 4 ? 3 : (MT == 3 ? 3 : 4))) conv_kernel(ConvArgs a) {
     constexpr int TM = 32 * MT, TMP = TM + 4, Q = KC / 4;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int halo = (KT - 1) * a.dil;
@@ -428,7 +428,7 @@ static int launch_conv(hipStream_t s, const ConvArgs& a, int B) {
     // barrier pair per stage is what they pay for -- 32-channel stages there (round 3, per-op profile at 32 chunks:
     // the pre-transformer's 1024 -> 512 projections 69-75 -> 58 us, ConvNeXt 4096 -> 1024 0.60 / 0.88 -> 0.56 / 0.83 ms).
     static const int kc_max = getenv("Q3_VOC_KC_MAX") ? atoi(getenv("Q3_VOC_KC_MAX")) : 16;
-    const bool short_act = (long)a.Lc * B <= 16384 && c % 32 == 0 && a.K <= 2;
+    const bool short_act = (long)a.Lc * B <= 16384 && a.M <= 4096 && c % 32 == 0 && a.K <= 2;   // (not the 1536 -> 768 x 8 transposed conv: 2.92 -> 3.10 ms)
     if (kc_max < 32 && !short_act && c % 16 == 0 && (a.K == 1 || a.K == 2))
         return a.K == 1 ? launch_conv_mt<1, 16>(s, a, B) : launch_conv_mt<2, 16>(s, a, B);
     switch (a.K) {
