@@ -382,9 +382,21 @@ def kv_bytes_per_step(n_text, frames, cfg):
     return sum(per_pos * t for t in t_avg) + cp * len(n_text)
 
 
-# HBM bytes per launch of the gate/up kernel from the PMC counters (profiles/r02_pmc_linear.md: FETCH_SIZE
-# doubled as the gfx950 guide prescribes + WRITE_SIZE), keyed by the row count it was collected at
-PMC_TRAFFIC_GATEUP = {32: 13.22e6 + 0.197e6, 1: 12.89e6 + 0.012e6}
+def pmc_traffic_gateup(rows):
+    """HBM bytes per launch of the gate/up kernel from the committed PMC passes of the final build -- profiles/r03_pmc_linear.json,
+    which scripts/pmc_linear_table.py derives from the raw rocprofv3 rows (r03_pmc_{fetch,write}_counter_collection.csv: FETCH_SIZE
+    doubled as the gfx950 guide prescribes + WRITE_SIZE; tests/test_profiles.py re-derives it).  -> (talker variant: cold weights,
+    nt loads; in-graph code-predictor variant: weights resident in the Infinity Cache), None where no pass covers the row count."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_linear.json")) as f:
+            js = json.load(f)
+    except OSError:
+        return None, None
+    mt = 2 if rows > 16 else 1
+    t = js.get(f"linear_kernel<2, {mt}, 4, 8, 1, 2, true>")
+    c = js.get(f"linear_kernel<2, {mt}, 4, 8, 1, 2, false>")
+    ok = lambda e: e is not None and int(e["rows"]) == int(rows)
+    return (float(t["hbm_bytes_per_launch"]) if ok(t) else None, float(c["hbm_bytes_per_launch"]) if ok(c) else None)
 
 
 def dominant_kernel_roofline(rows, cache, timeline=True):
@@ -419,9 +431,12 @@ def dominant_kernel_roofline(rows, cache, timeline=True):
         us = float(hiplib.load_test().q3t_bench_linear(int(rows), N, K, 1, 2, 1, 48, 480))
         how = "stand-alone back-to-back launches over 48 weight copies (q3t_bench_linear), HIP events"
     ach = algo / (us * 1e-6) / 1e9
+    t_talker, t_cp = pmc_traffic_gateup(rows)
     out = {"kernel": "linear_kernel<gate/up + SwiGLU> (RMSNorm folded, MFMA 16x16x32 f16, split-K over waves)",
            "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC_GATEUP.get(int(rows)),
+           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": t_talker, "traffic_cache_resident": t_cp,
+           "traffic_source": "profiles/r03_pmc_linear.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE per launch; talker variant = cold "
+                             "weights / nt loads, cache_resident = the in-graph code-predictor variant)",
            "algorithmic_bytes_per_launch": int(algo), "avg_launch_us": round(us, 3), "rows": int(rows), "measured": how}
     return out, table
 

@@ -557,13 +557,14 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int NBUF, int PRO, int EPI>
+template <int BM, int BN, int NBUF, int PRO, int EPI, int KS = 2>
 __global__ void __launch_bounds__(512) gemm_glds_kernel(LinArgs a) {
     // 8 waves: two groups of 4 (2 x 2 over the tile).  A stage holds KS = 2 k-blocks (64 k); group g multiplies
     // k-block g of every stage, so each SIMD carries two waves whose LDS reads and MFMAs interleave (with one wave
     // per SIMD they alternate: the tile ran at ~2800 cycles per stage against 512 of MFMA work).  The two groups'
     // accumulators meet once, through LDS, in a fixed order (even k-blocks + odd k-blocks).
-    constexpr int RA = BM / 16, RB = BN / 16, KS = 2;           // fragments of the tile; k-blocks (32 k) per stage
+    constexpr int RA = BM / 16, RB = BN / 16;                   // fragments of the tile; KS k-blocks (32 k) per stage, KS / 2 per group
+    static_assert(KS % 2 == 0, "two wave groups share a stage's k-blocks");
     constexpr int NF = (RA + RB) * KS, FPW = NF / 8;            // fragments per stage; per wave to fetch
     constexpr int WM = BM / 32, WN = BN / 32;
     constexpr int PF = NBUF - 1;                                // ring size NBUF; stages in flight
@@ -635,16 +636,20 @@ __global__ void __launch_bounds__(512) gemm_glds_kernel(LinArgs a) {
         asm volatile("" ::: "memory");
         if (ks + PF < NST) issue(ks + PF);     // into the buffer stage ks - 1 occupied
         const h8* cur = lds + (size_t)(ks % NBUF) * NF * 64;
-        h8 af[WM], bf[WN];
 #pragma unroll
-        for (int i = 0; i < WM; i++) af[i] = cur[((wm * WM + i) * KS + grp) * 64 + lane];
+        for (int kk = 0; kk < KS / 2; kk++) {
+            const int kb = grp * (KS / 2) + kk;      // this group's k-blocks of the stage
+            h8 af[WM], bf[WN];
 #pragma unroll
-        for (int j = 0; j < WN; j++) bf[j] = cur[(RA * KS + (wn * WN + j) * KS + grp) * 64 + lane];
+            for (int i = 0; i < WM; i++) af[i] = cur[((wm * WM + i) * KS + kb) * 64 + lane];
 #pragma unroll
-        for (int i = 0; i < WM; i++)
+            for (int j = 0; j < WN; j++) bf[j] = cur[(RA * KS + (wn * WN + j) * KS + kb) * 64 + lane];
 #pragma unroll
-            for (int j = 0; j < WN; j++)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < WM; i++)
+#pragma unroll
+                for (int j = 0; j < WN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
     }
     // ---- the odd k-blocks' accumulators (group 1) join the even ones (group 0) through the now idle ring ----
     __builtin_amdgcn_s_barrier();              // every wave is done reading the last stage
@@ -687,15 +692,25 @@ static int launch_gemm_t(hipStream_t s, const LinArgs& a) {
     b.tl_node = tl_next_node();
     dim3 grid(((a.M - a.m_begin + BM - 1) / BM) * (a.N / BN));   // 1-D: the kernels map it to tiles XCD by XCD
     if (g_gemm_glds) {
-        constexpr int NBUF = (BM + BN) > 256 ? 3 : 4;                                      // the ring must fit 160 KiB
-        constexpr size_t lds2 = (size_t)NBUF * ((BM + BN) / 16) * 2 * 1024 + BM * 4;       // ring + post[BM]
+#ifndef Q3_GEMM_KS_SMALL
+#define Q3_GEMM_KS_SMALL 4
+#endif
+        // (round 3: a 9-deep ring for the 64 x 64 tiles -- 128 KB in flight instead of 48 -- changed nothing, 3.17 vs 3.10 ms
+        // per 971-row prefill: those tiles are bound by the per-stage barrier, not by bytes in flight; hence KS below)
+        constexpr int NBUF = (BM + BN) > 256 ? 3 : 4;
+        constexpr int KS2 = (BM + BN) <= 128 ? Q3_GEMM_KS_SMALL : 2;                        // k-blocks (32 k) per stage
+        constexpr size_t lds2 = (size_t)NBUF * ((BM + BN) / 16) * KS2 * 1024 + BM * 4;     // ring + post[BM]
         static bool attr2 = false;
         if (!attr2) {
-            Q3_HIP(hipFuncSetAttribute((const void*)gemm_glds_kernel<BM, BN, NBUF, PRO, EPI>,
+            Q3_HIP(hipFuncSetAttribute((const void*)gemm_glds_kernel<BM, BN, NBUF, PRO, EPI, KS2>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2), -1);
             attr2 = true;
         }
-        hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, NBUF, PRO, EPI>), grid, dim3(512), lds2, s, b);
+        if ((a.K >> 5) % KS2) {
+            Q3_LOG("launch_gemm: K=%d is no multiple of %d", a.K, 32 * KS2);
+            return -1;
+        }
+        hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, NBUF, PRO, EPI, KS2>), grid, dim3(512), lds2, s, b);
     } else {
         hipLaunchKernelGGL((gemm_kernel<BM, BN, KS, PRO, EPI>), grid, dim3(256), lds, s, b);
     }
