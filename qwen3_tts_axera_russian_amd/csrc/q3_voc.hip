@@ -423,12 +423,14 @@ static int launch_conv(hipStream_t s, const ConvArgs& a, int B) {
     // 32-channel variants of the 128-row tile spill 27-35 registers).  Measured at 32 chunks: 384 -> 384 k1 1.74 -> 1.28 ms,
     // 768 -> 768 k1 1.06 -> 0.84, the ConvNeXt 1024 -> 4096 convs 0.39 / 0.74 -> 0.35 / 0.64; Q3_VOC_KC_MAX=32 restores
     // the 32-channel stages (channel counts that are no multiple of 16 take them or the 8-channel ones anyway).
-    // Short activations (the 12.5 / 25 / 50 Hz stages: <= 16 K columns in all) are the other way round: their tiles are
+    // Short activations (the 12.5 / 25 / 50 Hz stages: <= 512 columns per chunk) are the other way round: their tiles are
     // 32-64 rows (launch_conv_mt shrinks them until the grid covers the chip), a stage is a handful of MFMAs, and the
     // barrier pair per stage is what they pay for -- 32-channel stages there (round 3, per-op profile at 32 chunks:
     // the pre-transformer's 1024 -> 512 projections 69-75 -> 58 us, ConvNeXt 4096 -> 1024 0.60 / 0.88 -> 0.56 / 0.83 ms).
     static const int kc_max = getenv("Q3_VOC_KC_MAX") ? atoi(getenv("Q3_VOC_KC_MAX")) : 16;
-    const bool short_act = (long)a.Lc * B <= 16384 && a.M <= 4096 && c % 32 == 0 && a.K <= 2;   // (not the 1536 -> 768 x 8 transposed conv: 2.92 -> 3.10 ms)
+    // (the rule looks at ONE chunk's columns, never at the batch: a chunk must decode to the same bits alone and inside a
+    // batch, and with two taps the stage width changes the order in which taps and channels are summed)
+    const bool short_act = a.Lc <= 512 && a.M <= 4096 && c % 32 == 0 && a.K <= 2;   // (not the 1536 -> 768 x 8 transposed conv: 2.92 -> 3.10 ms)
     if (kc_max < 32 && !short_act && c % 16 == 0 && (a.K == 1 || a.K == 2))
         return a.K == 1 ? launch_conv_mt<1, 16>(s, a, B) : launch_conv_mt<2, 16>(s, a, B);
     switch (a.K) {
