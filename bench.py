@@ -435,8 +435,9 @@ def dominant_kernel_roofline(rows, cache, timeline=True):
     out = {"kernel": "linear_kernel<gate/up + SwiGLU> (RMSNorm folded, MFMA 16x16x32 f16, split-K over waves)",
            "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": t_talker, "traffic_cache_resident": t_cp,
-           "traffic_source": "profiles/r03_pmc_linear.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE per launch; talker variant = cold "
-                             "weights / nt loads, cache_resident = the in-graph code-predictor variant)",
+           "traffic_source": "profiles/r03_pmc_linear.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE per launch = what the L2s request "
+                             "from the fabric; talker variant = cold weights / nt loads, cache_resident = the in-graph code-predictor "
+                             "variant, whose requests the Infinity Cache can serve: the counter does not tell)",
            "algorithmic_bytes_per_launch": int(algo), "avg_launch_us": round(us, 3), "rows": int(rows), "measured": how}
     return out, table
 

@@ -39,8 +39,8 @@ struct ConvArgs {
     const float* res = nullptr;       // [B][Cout][L] added in the epilogue
     int gelu = 0;                     // exact GELU applied to the input (ConvNeXt's second pointwise conv)
     int Cin = 0, M = 0, K = 0, dil = 1, Lin = 0, stride = 1, Cout = 0, clamp = 0;
-    // Activations are [B][C][ld]: rows of L valid columns at a pitch ld = L rounded up to 4 floats, so that every row
-    // starts 16-byte aligned whatever L is (the transposed convs of the decoder family trim k - s samples at both ends:
+    // Activations are [B][C][ld]: rows of L valid columns at a pitch ld = L rounded up to 32 floats (pitch4()), so that
+    // every row starts on a 128-byte line whatever L is (the transposed convs of the decoder family trim k - s samples at both ends:
     // 64 frames -> 256 -> 2040 -> 10195 -> 40776 -> 122325 columns).  Pad columns hold junk that only ever feeds pad
     // columns: every op is causal per column (a GEMM column depends on its own B column only).
     int ldx = 0, ldy = 0;
@@ -1218,7 +1218,10 @@ struct VocOp {
     int lt = 0, rt = 0;     // transposed conv: samples trimmed from the (L - 1) * stride + k outputs, left / right
 };
 
-static inline long pitch4(long L) { return (L + 3) & ~3L; }
+// row pitch of an activation: L rounded up to 32 floats = one 128-byte line, so that rows (and the 32-column runs a wave
+// stores) start on a line whatever L is -- with a 16-byte pitch the fused units' stores straddled two lines and WRITE_SIZE
+// counted 4.5-4.6 B per element instead of 4.00 (profiles/r03_pmc_vocoder.md); the kernels need 4 | pitch only
+static inline long pitch4(long L) { return (L + 31) & ~31L; }
 // kept outputs of a transposed conv over L input columns
 static inline long convt_out(const VocOp& op, long L) { return (L - 1) * op.p0 + op.k - op.lt - op.rt; }
 // columns of its polyphase GEMM that reach a kept output (virtual row p of column l lands at l * s + p - lt)

@@ -6,7 +6,11 @@ FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts a wide (16 B per
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kname import pretty  # noqa: E402
 
 SHAPES = [  # (kernel-name fragment, rows, label, algorithmic bytes: weights, fp16 activations in, output)
     ("linear_kernel<2, 2, 4, 8, 1, 2, true>", 32, "gate/up + SwiGLU, talker (cold weights, nt loads)", 6144 * 1024 * 2, 32 * 1024 * 2, 32 * 3072 * 2),
@@ -21,7 +25,7 @@ SHAPES = [  # (kernel-name fragment, rows, label, algorithmic bytes: weights, fp
 def load(f):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+        acc[pretty(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     return acc
 
 
@@ -49,11 +53,13 @@ def main():
           f"{tag}_pmc_write_counter_collection.csv; machine-readable: {tag}_pmc_linear.json (what `bench.py` puts into `roofline.traffic`).\n",
           "| kernel | rows | FETCH_SIZE KiB | read bytes (x2 x1024) | WRITE_SIZE KiB | algorithmic bytes (weights + activations + output) | measured / algorithmic |",
           "|---|---|---|---|---|---|---|"] + rows
-    md.append("\nThe talker's launches read their weights once from HBM (ratio ~1.0: no wasted re-reads; the activation tile is fetched once per")
-    md.append("XCD L2).  The SAME kernel inside the frame graph's code-predictor passes (default-policy loads, its five layers' 63 MB of")
-    md.append("gate/up weights re-streamed 15 times per frame) is served from the 256 MB Infinity Cache: the counters show what still")
-    md.append("comes from HBM -- the algorithmic figure SURVEY.md 8d asks for counts those bytes in full (`roofline.achieved`), the")
-    md.append("measured one is `roofline.traffic_cache_resident`.")
+    md.append("\nEvery launch reads its weights once (ratio ~1.0 for gate/up and q|k|v: no wasted re-reads); the activation tile is fetched")
+    md.append("once per XCD L2, which is what lifts the N = 1024 projections to 1.2 (8 x 128 / 192 KB of activations against 4.2 / 6.3 MB")
+    md.append("of weights).  FETCH_SIZE counts what the L2s request from the fabric: it is the same 13.2 MB for the gate/up kernel as the")
+    md.append("talker runs it (cold weights, non-temporal loads) and as the code predictor runs it inside the frame graph (default-policy")
+    md.append("loads; its five layers' 63 MB are re-streamed 15 times per frame and fit the 256 MB Infinity Cache) -- the counter does not")
+    md.append("tell an Infinity Cache hit from an HBM read, so `roofline.traffic` and `roofline.traffic_cache_resident` are both L2-side")
+    md.append("figures; whether the second one reaches HBM is not measurable with these counters.")
     open(f"profiles/{tag}_pmc_linear.md", "w").write("\n".join(md) + "\n")
     json.dump(js, open(f"profiles/{tag}_pmc_linear.json", "w"), indent=1)
     print("\n".join(md))

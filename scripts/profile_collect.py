@@ -12,17 +12,28 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def first(pattern):
-    g = sorted(glob.glob(pattern, recursive=True))
+    g = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)     # gpurun MERGES into gpurun_out/: take the newest run
     if not g:
         raise SystemExit(f"nothing matches {pattern}")
-    return g[0]
+    return g[-1]
 
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     O, P = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
     cp = lambda src, dst: shutil.copyfile(src, os.path.join(P, dst))
-    cp(os.path.join(O, "bench_kernel_stats.csv"), f"{tag}_bench_kernel_stats.csv")
+    # kernel-stats summary with readable names (rocprofv3 prints kernels with plain-pointer arguments mangled, with a .kd suffix)
+    import csv as _csv
+    rows = list(_csv.DictReader(open(os.path.join(O, "bench_kernel_stats.csv"))))
+    key = "Name" if rows and "Name" in rows[0] else list(rows[0].keys())[0]
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from kname import pretty
+    for r in rows:
+        r[key] = pretty(r[key])
+    with open(os.path.join(P, f"{tag}_bench_kernel_stats.csv"), "w", newline="") as fh:
+        w = _csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(rows)
     cp(first(os.path.join(O, "pmc_lin_FETCH_SIZE", "**", "*counter_collection.csv")), f"{tag}_pmc_fetch_counter_collection.csv")
     cp(first(os.path.join(O, "pmc_lin_WRITE_SIZE", "**", "*counter_collection.csv")), f"{tag}_pmc_write_counter_collection.csv")
     cp(first(os.path.join(O, "pmc_voc_FETCH_SIZE", "**", "*counter_collection.csv")), f"{tag}_pmc_vocoder_fetch_counter_collection.csv")

@@ -55,22 +55,20 @@ def test_profiled_kernel_names_are_kernels_of_the_built_library():
     if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
         import pytest
         pytest.skip("llvm-readelf not installed")
+    import re  # noqa: F401
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from kname import pretty
     syms = set(build.kernel_resources(LIB_PATH)) | set(build.kernel_resources(LIB_PATH.replace("libqwen3tts.so", "libqwen3tts_test.so")))
-    demangled = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(sorted(syms)), text=True).splitlines()
-    built = {re.sub(r"\(.*$", "", d).replace("void ", "").replace("q3::", "").strip() for d in demangled}
+    built = {pretty(s_) for s_ in syms}
     named = set()
     for f in (f"{TAG}_pmc_vocoder_fetch_counter_collection.csv", f"{TAG}_pmc_vocoder_mfma_counter_collection.csv",
               f"{TAG}_pmc_fetch_counter_collection.csv"):
         for r in csv.DictReader(open(os.path.join(P, f))):
-            named.add(re.sub(r"\(.*$", "", r["Kernel_Name"]).replace("void ", "").replace("q3::", "").strip())
+            named.add(pretty(r["Kernel_Name"]))
     for r in csv.DictReader(open(os.path.join(P, f"{TAG}_bench_kernel_stats.csv"))):
-        n = r.get("Name") or r.get("kernel") or list(r.values())[0]
-        n = re.sub(r"\(.*$", "", n).replace("void ", "").replace("q3::", "").strip()
-        if "kernel" in n and not n.startswith("__amd"):
-            named.add(n)
-    named = {n for n in named if not n.startswith("__amd") and n}
-    # mangled names (rocprofv3 prints some kernels undemangled) are compared as they are
-    missing = sorted(n for n in named if n not in built and n not in syms)
+        named.add(pretty(r.get("Name") or list(r.values())[0]))
+    named = {n for n in named if n and not n.startswith("__amd") and "rocclr" not in n}
+    missing = sorted(n for n in named if n not in built)
     assert len(named) >= 15 and not missing, missing
 
 
