@@ -58,19 +58,33 @@ static int g_voc_split = 1;    // 1 (default): split-precision fp16 MFMA path wh
 static int g_voc_max_wgs = 0;  // 0 = one workgroup per tile; >0 caps the grid (persistent tile loop)
 constexpr int VKC = 8;     // input channels per LDS stage
 constexpr int VTN = 128;   // output columns per workgroup (4 waves x 32)
+// LDS row pitches of the staged operands.  An MFMA operand read is 64 lanes x 4 B: lanes 0-31 walk 32 consecutive floats of
+// row ci, lanes 32-63 of row ci + 1; the two halves hit disjoint banks when the row pitch is 32 mod 64 floats.
+// (round 3, per-op profile at 32 chunks: the input tile's pitch padded that way removes every bank conflict of the 7-tap and fused
+// kernels -- SQ_LDS_BANK_CONFLICT 0 -- and takes 1.5 % off the decode, 92.5 -> 91.1 ms; padding the weight rows too costs LDS
+// and gains nothing)
+#ifndef Q3_VOC_XPAD
+#define Q3_VOC_XPAD 1
+#endif
+#ifndef Q3_VOC_WPAD
+#define Q3_VOC_WPAD 0
+#endif
+__host__ __device__ constexpr int voc_wpitch(int TM) { return Q3_VOC_WPAD ? (TM % 64 == 0 ? TM + 32 : (TM % 64 == 32 ? TM : TM + 4)) : TM + 4; }
+__host__ __device__ inline int voc_xpitch(int XW) { return Q3_VOC_XPAD ? ((XW + 31) / 64) * 64 + 32 : XW; }
 
 // conv_kernel<MT, KT, KC>: MT 32-row MFMA tiles per wave, KT taps, KC input channels per LDS stage.
 // Staging goes global -> LDS directly; ~4 workgroups per CU hide its latency (a register-staged software
 // pipeline was tried: 199-256 VGPRs, one workgroup per SIMD, 1.6x slower at 32 chunks).
 template <int MT, int KT, int KC, bool CT = false>   // CT: transposed conv (stride > 1, no residual), stores go through an LDS slab
 __global__ void __launch_bounds__(256, (KC >= 32 && MT >= 3) ? 2 : (MT >= 4 ? 3 : (MT == 3 ? 3 : 4))) conv_kernel(ConvArgs a) {
-    constexpr int TM = 32 * MT, TMP = TM + 4, Q = KC / 4;
+    constexpr int TM = 32 * MT, TMP = voc_wpitch(TM), Q = KC / 4;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int halo = (KT - 1) * a.dil;
     const int XW = VTN + halo;  // staged columns: l0-halo .. l0+127
+    const int XP = voc_xpitch(XW);     // their row pitch in LDS
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Ws = lds;                   // [KT][KC][TMP]
-    float* Xs = lds + KT * KC * TMP;   // [KC][XW]
+    float* Xs = lds + KT * KC * TMP;   // [KC][XP]
     // persistent over output tiles (the grid may be capped, see voc_set_max_workgroups)
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int lx = tile % a.tiles_l, my = (tile / a.tiles_l) % a.tiles_m, b = tile / (a.tiles_l * a.tiles_m);
@@ -161,7 +175,7 @@ __global__ void __launch_bounds__(256, (KC >= 32 && MT >= 3) ? 2 : (MT >= 4 ? 3 
                             v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
                         }
                         if (l0 + c4 >= Lcols) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        *(float4*)(Xs + xci * XW + c4) = v;
+                        *(float4*)(Xs + xci * XP + c4) = v;
                     }
                 }
             } else {
@@ -189,7 +203,7 @@ __global__ void __launch_bounds__(256, (KC >= 32 && MT >= 3) ? 2 : (MT >= 4 ? 3 
                             }
                             if (a.gelu) v = gelu_erf(v);
                             if (l < 0 || l >= a.Lin) v = 0.f;
-                            Xs[xci * XW + col] = v;
+                            Xs[xci * XP + col] = v;
                         }
                     }
                 }
@@ -205,7 +219,7 @@ __global__ void __launch_bounds__(256, (KC >= 32 && MT >= 3) ? 2 : (MT >= 4 ? 3 
 #pragma unroll
                 for (int kk = 0; kk < KC; kk += 2) {
                     const int ci = kk + (lane >> 5);
-                    const float bv = Xs[ci * XW + off];
+                    const float bv = Xs[ci * XP + off];
 #pragma unroll
                     for (int mt = 0; mt < MT; mt++) {
                         const float av = Ws[(k * KC + ci) * TMP + mt * 32 + (lane & 31)];
@@ -282,13 +296,13 @@ static int launch_conv_t(hipStream_t s, const ConvArgs& a, int B) {
     if constexpr (!CT && KT <= 2) {
         if (a.stride > 1 && a.res == nullptr) return launch_conv_t<MT, KT, KC, true>(s, a, B);
     }
-    constexpr int TM = 32 * MT, TMP = TM + 4;
+    constexpr int TM = 32 * MT, TMP = voc_wpitch(TM);
     const int halo = (KT - 1) * a.dil;
     if (a.dil > 9) {
         Q3_LOG("voc conv: dilation %d > 9 is not built", a.dil);
         return -1;
     }
-    size_t lds = ((size_t)KT * KC * TMP + (size_t)KC * (VTN + halo)) * sizeof(float);
+    size_t lds = ((size_t)KT * KC * TMP + (size_t)KC * voc_xpitch(VTN + halo)) * sizeof(float);
     if (CT && lds < (size_t)32 * (VTN + 1) * sizeof(float)) lds = (size_t)32 * (VTN + 1) * sizeof(float);   // store slab
     // experiment knob: Q3_VOC_LDS_PAD=bytes raises every conv launch's LDS request, i.e. lowers the vocoder's
     // residency per CU evenly (room for the frame loop's workgroups when the two run side by side)
@@ -469,13 +483,13 @@ static int g_voc_fuse = 1;   // 1 (default): residual units at <= 192 channels r
 
 template <int MT>
 __global__ void __launch_bounds__(256, MT <= 3 ? 3 : 2) resunit_kernel(ResUnitArgs a) {
-    constexpr int C = 32 * MT, KT = 7, KC = 8, TMP = C + 4;
+    constexpr int C = 32 * MT, KT = 7, KC = 8, TMP = voc_wpitch(C);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int halo = (KT - 1) * a.dil, XW = VTN + halo;
+    const int halo = (KT - 1) * a.dil, XW = VTN + halo, XP = voc_xpitch(XW);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Ws = lds;                   // [KT][KC][TMP]; later one row tile of the 1x1 weights [C/2][64]
-    float* Xs = lds + KT * KC * TMP;   // [KC][XW]
-    float* Ps = Xs + KC * XW;          // [4][C]: b7, al1, ib1, b1
+    float* Xs = lds + KT * KC * TMP;   // [KC][XP]
+    float* Ps = Xs + KC * XP;          // [4][C]: b7, al1, ib1, b1
     for (int i = tid; i < C; i += 256) {
         Ps[i] = a.b7 ? a.b7[i] : 0.f;
         Ps[C + i] = a.al1[i];
@@ -529,7 +543,7 @@ __global__ void __launch_bounds__(256, MT <= 3 ? 3 : 2) resunit_kernel(ResUnitAr
                     const float sn = __sinf(al * xv[j]);
                     float v = xv[j] + ib * (sn * sn);
                     if (l < 0 || l >= a.Lin) v = 0.f;
-                    Xs[xci * XW + col] = v;
+                    Xs[xci * XP + col] = v;
                 }
             }
             __syncthreads();
@@ -539,7 +553,7 @@ __global__ void __launch_bounds__(256, MT <= 3 ? 3 : 2) resunit_kernel(ResUnitAr
 #pragma unroll
                 for (int kk = 0; kk < KC; kk += 2) {
                     const int ci = kk + (lane >> 5);
-                    const float bv = Xs[ci * XW + off];
+                    const float bv = Xs[ci * XP + off];
 #pragma unroll
                     for (int mt = 0; mt < MT; mt++) {
                         const float av = Ws[(k * KC + ci) * TMP + mt * 32 + (lane & 31)];
@@ -606,7 +620,7 @@ static int launch_resunit_t(hipStream_t s, ResUnitArgs a, int B) {
     constexpr int C = 32 * MT;
     const int halo = 6 * a.dil;
     if (a.dil > 9) return -1;
-    const size_t lds = ((size_t)7 * 8 * (C + 4) + (size_t)8 * (VTN + halo) + 4 * C) * sizeof(float);
+    const size_t lds = ((size_t)7 * 8 * voc_wpitch(C) + (size_t)8 * voc_xpitch(VTN + halo) + 4 * C) * sizeof(float);
     a.tiles_l = (a.Lin + VTN - 1) / VTN;
     a.n_tiles = a.tiles_l * B;
     int grid = a.n_tiles;

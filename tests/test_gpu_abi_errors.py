@@ -87,4 +87,19 @@ def test_vocoder_request_bounds(gpu_lib):
     pcm = np.zeros(1000, np.int16)
     assert lib.voc_synthesize(h, codes.ctypes.data_as(hiplib.i64p), 0, pcm.ctypes.data_as(hiplib.i16p), hiplib.iptr(ns)) == -1
     assert lib.voc_synthesize_max_samples(h, 0) == 0
+    # the batched walk: null arguments, an empty utterance, no utterances, a table that trims -> chunk_samples < 64 * 1920
+    assert 0 < lib.voc_chunk_samples(h) <= 64 * 1920 and lib.voc_chunk_samples(None) == 0
+    nn = np.array([3, 0], np.int32)
+    off = np.zeros(3, np.int64)
+    big = np.full(200000, 7, np.int16)
+    c2 = np.zeros((3, 16), np.int64)
+    i64 = lambda a: a.ctypes.data_as(hiplib.i64p)
+    assert lib.voc_synthesize_batch(h, i64(c2), hiplib.iptr(nn), 2, big.ctypes.data_as(hiplib.i16p), len(big), i64(off)) == -1
+    assert lib.voc_synthesize_batch(h, i64(c2), hiplib.iptr(nn), 0, big.ctypes.data_as(hiplib.i16p), len(big), i64(off)) == -1
+    assert lib.voc_synthesize_batch(None, i64(c2), hiplib.iptr(nn), 1, big.ctypes.data_as(hiplib.i16p), len(big), i64(off)) == -1
+    assert lib.voc_synthesize_batch(h, None, hiplib.iptr(nn), 1, big.ctypes.data_as(hiplib.i16p), len(big), i64(off)) == -1
+    assert (big == 7).all()
+    assert lib.voc_synthesize_batch_max_samples(h, hiplib.iptr(nn), 0) == 0
+    assert lib.voc_synthesize_batch(h, i64(c2), hiplib.iptr(nn), 1, big.ctypes.data_as(hiplib.i16p), len(big), i64(off)) == 0
+    assert list(off[:2]) == [0, 3 * 1920] and lib.voc_last_batch_chunks(h) == 1 and lib.voc_last_batch_ms(h) > 0
     lib.voc_free(h)
