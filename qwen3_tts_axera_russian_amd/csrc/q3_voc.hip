@@ -213,6 +213,11 @@ __global__ void __launch_bounds__(256, (KC >= 32 && MT >= 3) ? 2 : (MT >= 4 ? 3 
                 load_w(ci0 + KC);
                 load_x1(ci0 + KC);
             }
+            // (round 3 probes of this loop, all measured per op at 32 chunks: the compiler's own schedule -- two A reads, wait, two
+            // MFMAs, twice per step -- beats "all reads, one wait, four MFMAs" by 5 % (forced with sched_barrier: 91.1 -> 96.4 ms
+            // per decode), and a hand-made software pipeline that issues half-step t + 1's LDS reads before half-step t's MFMAs
+            // is worth 1 % at 17 spilled registers; 3 workgroups per CU run as fast as 4.  LDS latency and occupancy are not
+            // what holds the 7-tap convs at 81 % MFMA-busy.)
 #pragma unroll 1
             for (int k = 0; k < KT; k++) {
                 const int off = halo - (KT - 1 - k) * a.dil + w * 32 + (lane & 31);
