@@ -75,7 +75,11 @@ __host__ __device__ inline int voc_xpitch(int XW) { return Q3_VOC_XPAD ? ((XW + 
 // conv_kernel<MT, KT, KC>: MT 32-row MFMA tiles per wave, KT taps, KC input channels per LDS stage.
 // Staging goes global -> LDS directly; ~4 workgroups per CU hide its latency (a register-staged software
 // pipeline was tried: 199-256 VGPRs, one workgroup per SIMD, 1.6x slower at 32 chunks).
-template <int MT, int KT, int KC, bool CT = false>   // CT: transposed conv (stride > 1, no residual), stores go through an LDS slab
+// ACT: what is applied to the input while it is staged -- 0 nothing, 1 Snake, 2 exact GELU, 3 decided at run time (a.alpha /
+// a.gelu).  Compiled in for the one-tap convs (round 3, per-op profile at 32 chunks: the Snake 1 x 1 convs that close the 768- /
+// 384-channel residual units 0.82 -> 0.75 and 1.27 -> 1.11 ms); for two and more taps the run-time form is the faster one
+// (7-tap 126 vs 124 TFLOP/s, transposed convs 105 vs 99: the specialised kernels are scheduled worse), so those keep it.
+template <int MT, int KT, int KC, bool CT = false, int ACT = 3>   // CT: transposed conv (stride > 1, no residual), stores go through an LDS slab
 __global__ void __launch_bounds__(256, (KC >= 32 && MT >= 3) ? 2 : (MT >= 4 ? 3 : (MT == 3 ? 3 : 4))) conv_kernel(ConvArgs a) {
     constexpr int TM = 32 * MT, TMP = voc_wpitch(TM), Q = KC / 4;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -119,7 +123,7 @@ __global__ void __launch_bounds__(256, (KC >= 32 && MT >= 3) ? 2 : (MT >= 4 ? 3 
             }
             // the input line buffer (causal: columns left of 0 are zero; Snake(0) = 0 so padding commutes).  A thread
             // stays on ONE channel of the stage (LPC lanes per channel), so its Snake parameters are two registers
-            if (a.alpha) { al = a.alpha[ci0 + xci]; ib = a.inv_beta[ci0 + xci]; }
+            if (ACT == 1 || (ACT == 3 && a.alpha)) { al = a.alpha[ci0 + xci]; ib = a.inv_beta[ci0 + xci]; }
         };
         auto load_x1 = [&](int ci0) {   // one tap: no halo, the tile's 128 columns start 16-byte aligned
 #pragma unroll
@@ -164,14 +168,14 @@ __global__ void __launch_bounds__(256, (KC >= 32 && MT >= 3) ? 2 : (MT >= 4 ? 3 
                     const int c4 = (xl + j * LPC) * 4;
                     if (c4 < VTN) {
                         float4 v = xv1[j];
-                        if (a.alpha) {
+                        if (ACT == 1 || (ACT == 3 && a.alpha)) {
                             float sn;
                             sn = __sinf(al * v.x); v.x = v.x + ib * (sn * sn);
                             sn = __sinf(al * v.y); v.y = v.y + ib * (sn * sn);
                             sn = __sinf(al * v.z); v.z = v.z + ib * (sn * sn);
                             sn = __sinf(al * v.w); v.w = v.w + ib * (sn * sn);
                         }
-                        if (a.gelu) {
+                        if (ACT == 2 || (ACT == 3 && a.gelu)) {
                             v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
                         }
                         if (l0 + c4 >= Lcols) v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -197,11 +201,11 @@ __global__ void __launch_bounds__(256, (KC >= 32 && MT >= 3) ? 2 : (MT >= 4 ? 3 
                         if (col < XW) {
                             const int l = l0 - halo + col;
                             float v = xv[j];
-                            if (a.alpha) {
+                            if (ACT == 1 || (ACT == 3 && a.alpha)) {
                                 const float sn = __sinf(al * v);
                                 v = v + ib * (sn * sn);
                             }
-                            if (a.gelu) v = gelu_erf(v);
+                            if (ACT == 2 || (ACT == 3 && a.gelu)) v = gelu_erf(v);
                             if (l < 0 || l >= a.Lin) v = 0.f;
                             Xs[xci * XP + col] = v;
                         }
@@ -216,8 +220,11 @@ __global__ void __launch_bounds__(256, (KC >= 32 && MT >= 3) ? 2 : (MT >= 4 ? 3 
             // (round 3 probes of this loop, all measured per op at 32 chunks: the compiler's own schedule -- two A reads, wait, two
             // MFMAs, twice per step -- beats "all reads, one wait, four MFMAs" by 5 % (forced with sched_barrier: 91.1 -> 96.4 ms
             // per decode), and a hand-made software pipeline that issues half-step t + 1's LDS reads before half-step t's MFMAs
-            // is worth 1 % at 17 spilled registers; 3 workgroups per CU run as fast as 4.  LDS latency and occupancy are not
-            // what holds the 7-tap convs at 81 % MFMA-busy.)
+            // is worth 1 % at 17 spilled registers; 3 workgroups per CU run as fast as 4; co-resident workgroups started a quarter stage
+            // apart: no change.  With the staging of all but the first stage compiled out (wrong results, timing only) the 7-tap
+            // convs run at 139-140 TFLOP/s = 89 % and the transposed ones at 130-134 = 84 %, with or without the two barriers:
+            // the loop itself holds 11-16 % of the peak back, the staging WORK (global loads, Snake, LDS writes -- not the barriers)
+            // another 10 % of the 7-tap and 20 % of the transposed convs.)
 #pragma unroll 1
             for (int k = 0; k < KT; k++) {
                 const int off = halo - (KT - 1 - k) * a.dil + w * 32 + (lane & 31);
@@ -296,11 +303,20 @@ __global__ void __launch_bounds__(256, (KC >= 32 && MT >= 3) ? 2 : (MT >= 4 ? 3 
     }  // tile loop
 }
 
-template <int MT, int KT, int KC, bool CT = false>
+template <int MT, int KT, int KC, bool CT = false, int ACT = -1>
 static int launch_conv_t(hipStream_t s, const ConvArgs& a, int B) {
     if constexpr (!CT && KT <= 2) {
-        if (a.stride > 1 && a.res == nullptr) return launch_conv_t<MT, KT, KC, true>(s, a, B);
+        if (a.stride > 1 && a.res == nullptr) return launch_conv_t<MT, KT, KC, true, ACT>(s, a, B);
     }
+    if constexpr (ACT < 0) {      // the input activation becomes a template argument
+        if (a.alpha && a.gelu) {
+            Q3_LOG("voc conv: Snake and GELU on one input are not built");
+            return -1;
+        }
+        if constexpr (KT > 1) return launch_conv_t<MT, KT, KC, CT, 3>(s, a, B);
+        else return a.alpha ? launch_conv_t<MT, KT, KC, CT, 1>(s, a, B) : a.gelu ? launch_conv_t<MT, KT, KC, CT, 2>(s, a, B)
+                                                                             : launch_conv_t<MT, KT, KC, CT, 0>(s, a, B);
+    } else {
     constexpr int TM = 32 * MT, TMP = voc_wpitch(TM);
     const int halo = (KT - 1) * a.dil;
     if (a.dil > 9) {
@@ -316,7 +332,7 @@ static int launch_conv_t(hipStream_t s, const ConvArgs& a, int B) {
         lds = lds_pad;
         static bool attr = false;
         if (!attr) {
-            Q3_HIP(hipFuncSetAttribute((const void*)conv_kernel<MT, KT, KC, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), -1);
+            Q3_HIP(hipFuncSetAttribute((const void*)conv_kernel<MT, KT, KC, CT, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), -1);
             attr = true;
         }
     }
@@ -338,9 +354,10 @@ static int launch_conv_t(hipStream_t s, const ConvArgs& a, int B) {
     c.n_tiles = c.tiles_l * c.tiles_m * (c.flat_B > 0 ? 1 : B);
     int grid = c.n_tiles;
     if (g_voc_max_wgs > 0 && grid > g_voc_max_wgs) grid = g_voc_max_wgs;
-    hipLaunchKernelGGL((conv_kernel<MT, KT, KC, CT>), dim3(grid), dim3(256), lds, s, c);
+    hipLaunchKernelGGL((conv_kernel<MT, KT, KC, CT, ACT>), dim3(grid), dim3(256), lds, s, c);
     Q3_HIP(hipGetLastError(), -1);
     return 0;
+    }
 }
 
 template <int KT, int KC>
