@@ -218,6 +218,26 @@ def run_leg(eng, voc, prefixes, n_text, pad, frames, steps, warmup, sync_all):
 NEAR_TIE = 5e-3     # tests/test_gpu_engine.py: THE tolerance -- oracle top-1/top-2 gap below which two float pipelines may differ
 
 
+def verify_first_utterance(codes_f16, seed, frames=64):
+    """The batch-1 and long-form legs run the job's first utterance alone: its leading `frames` frames against the same fixture
+    (utterance 0 of tests/golden/bench_b32_f64.npz), identical up to a decision whose oracle gap is a near-tie."""
+    fx = os.path.join(ROOT, "tests", "golden", "bench_b32_f64.npz")
+    if not os.path.exists(fx):
+        return {"checked": False, "why": "fixture not found"}
+    g = np.load(fx)
+    if int(g["seed"]) != seed:
+        return {"checked": False, "why": f"fixture is for seed {int(g['seed'])}"}
+    ids, margins = g["ids"][0].astype(np.int32), g["margins"][0].astype(np.float32)
+    n = min(frames, ids.shape[0], codes_f16.shape[0])
+    eq = (codes_f16[:n] == ids[:n])
+    if eq.all():
+        return {"checked": True, "ok": True, "frames_compared": int(n), "identical_leading_frames": int(n)}
+    f = int(np.argmin(eq.all(axis=1)))
+    gap = float(margins[f, int(np.argmin(eq[f]))])
+    return {"checked": True, "ok": bool(gap < NEAR_TIE), "frames_compared": int(n), "identical_leading_frames": f,
+            "oracle_gap_at_the_divergence": round(gap, 6)}
+
+
 def verify_against_fixture(codes, B, F, seed, world, prefixes, n_text, pad):
     """Result check of the benchmark itself (the reference's client reports RTF for audio it really wrote,
     tts_client.py:268-271): the codec ids of the last TIMED step against the committed CPU-oracle trajectory of this
@@ -262,7 +282,7 @@ def verify_against_fixture(codes, B, F, seed, world, prefixes, n_text, pad):
     return res
 
 
-def longform_leg(lib, path, voc_path, prefix, n_text, pad, frames):
+def longform_leg(lib, path, voc_path, prefix, n_text, pad, frames, seed=1234):
     """BASELINE configs[4]: ONE utterance of >= 60 s of audio in latency mode -- prefill, `frames` frame steps, and the
     vocoder's overlap-crossfade chunk walk over the whole utterance (voc_synthesize_f32 = VocoderServer.synthesize,
     vocoder_server.py:73-121: 64-frame chunks stepping by 48).  First audio = prefill + the first 64 frames + their
@@ -293,7 +313,8 @@ def longform_leg(lib, path, voc_path, prefix, n_text, pad, frames):
         wall = time.perf_counter() - t0
         if timed:
             audio = int(ns[0]) / 24000.0
-            res = {"workload": f"configs[4]: one utterance, {frames} frames = {frames * FRAME_SEC:.1f} s of audio, latency mode "
+            res = {"verified": verify_first_utterance(codes.astype(np.int32), seed),
+                   "workload": f"configs[4]: one utterance, {frames} frames = {frames * FRAME_SEC:.1f} s of audio, latency mode "
                                "(prefill + frame loop + overlap-crossfade chunk walk, exact-fp32 vocoder)",
                    "frames": frames, "audio_s": round(audio, 2), "wall_s": round(wall, 4), "rtf": round(wall / audio, 5),
                    "first_audio_ms": round(t_first * 1e3, 2), "frame_loop_ms_per_frame": round(eng.last_run_ms / (frames - 64), 4)}
@@ -665,7 +686,10 @@ def main():
         if voc1 is not None:
             voc1.close()
         ab1 = step_w_bytes + kv_bytes_per_step(n_text[:1], F, cfg)
-        out["batch1"] = {"workload": "configs[1]: batch=1, same engine", "value": round(F * a.steps / dt1, 1),
+        v1 = verify_first_utterance(run_leg.last_codes[:, 0, :], a.seed, F)
+        if v1.get("checked") and not v1.get("ok"):
+            verified = dict(verified, checked=True, ok=False, batch1_failed=True)
+        out["batch1"] = {"workload": "configs[1]: batch=1, same engine", "verified": v1, "value": round(F * a.steps / dt1, 1),
                          "unit": "codec_frames/s", "rtf": round((dt1 / a.steps) / (F * FRAME_SEC), 5),
                          "ms_per_frame": round(frame_ms1, 4), "prefill_ms": round(prefill_ms1, 3),
                          "vocoder_ms_per_chunk": round(voc_ms1, 3),
@@ -673,7 +697,9 @@ def main():
         eng1.destroy()
     if rank == 0 and world == 1 and not a.no_longform and not a.no_vocoder:
         out["longform"] = longform_leg(lib, path, make_voc_pack(a.cache, a.seed, rank, barrier), prefixes[0], n_text[0], pad,
-                                       a.longform_frames)
+                                       a.longform_frames, a.seed)
+        if out["longform"]["verified"].get("checked") and not out["longform"]["verified"].get("ok"):
+            verified = dict(verified, checked=True, ok=False, longform_failed=True)
     if rank == 0 and world == 1 and not a.no_ragged and not a.no_vocoder:
         out["ragged"] = ragged_leg(lib, path, make_voc_pack(a.cache, a.seed, rank, barrier), B, a.seed)
     if rank == 0 and world == 1 and not a.no_cpu:
@@ -685,6 +711,7 @@ def main():
         if table is not None:
             out["frame_timeline"] = {k: {"n": v["n"], "span_us": v["mean_span_us"], "gap_us": v["mean_gap_before_us"]}
                                      for k, v in table["kinds"].items()}
+        out["verified"] = verified
         print(json.dumps(out), flush=True)
     R.close()
     if verified.get("checked") and not verified.get("ok"):
