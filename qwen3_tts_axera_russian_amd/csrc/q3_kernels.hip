@@ -743,6 +743,9 @@ static int launch_gemm(hipStream_t s, const LinArgs& a, int pro, int epi) {
     return -1;
 }
 
+// (round 3 probe: at <= 4 rows -- one utterance -- only the lanes of rows 0-3 fetching activation fragments, compiled in as a
+// template variant of linear_kernel and linear_narrow_kernel: 2.145-2.163 against 2.145-2.153 ms per frame, nothing; the
+// activation bytes are not what a one-row pass waits for)
 template <int NB16, int MT16, int KBW, int NW, int PRO, int EPI>
 static int launch_linear_t(hipStream_t s, const LinArgs& a) {
     return a.nt ? launch_linear_nt<NB16, MT16, KBW, NW, PRO, EPI, true>(s, a)
