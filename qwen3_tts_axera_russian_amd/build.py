@@ -89,8 +89,9 @@ def check_spills(lib_path: str, verbose: bool = False) -> None:
         raise RuntimeError("register spills in kernels that must not spill:\n  " + "\n  ".join(bad))
 
 
-def build(force: bool = False, verbose: bool = False, timeline: bool = False) -> str:
-    """timeline=True builds lib/libqwen3tts_tl.so with in-kernel time stamps (diagnostics only)."""
+def build(force: bool = False, verbose: bool = False, timeline: bool = False, refresh_timeline: bool = True) -> str:
+    """timeline=True builds lib/libqwen3tts_tl.so with in-kernel time stamps (diagnostics only).  refresh_timeline=False: the
+    product build leaves a stale timeline library alone (a caller that builds both side by side, __graft_entry__.build)."""
     os.makedirs(LIB, exist_ok=True)
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
@@ -144,7 +145,7 @@ def build(force: bool = False, verbose: bool = False, timeline: bool = False) ->
         # an existing diagnostic (timeline) build must not go stale: bench.py's in-graph launch durations come from it,
         # and it must export every symbol hiplib declares
         tl_out = os.path.join(LIB, "libqwen3tts_tl.so")
-        if os.path.exists(tl_out) and not _newer(tl_out, srcs + hdrs):
+        if refresh_timeline and os.path.exists(tl_out) and not _newer(tl_out, srcs + hdrs):
             build(force=force, verbose=verbose, timeline=True)
         alias = os.path.join(LIB, "llama_wrapper.so")
         if not os.path.exists(alias) or os.path.getmtime(alias) < os.path.getmtime(out):

@@ -313,7 +313,8 @@ static int launch_conv_t(hipStream_t s, const ConvArgs& a, int B) {
             Q3_LOG("voc conv: Snake and GELU on one input are not built");
             return -1;
         }
-        if constexpr (KT > 1) return launch_conv_t<MT, KT, KC, CT, 3>(s, a, B);
+        // (only the variant the long Snake 1 x 1 convs run is specialised: every further one is another kernel to compile)
+        if constexpr (!(KT == 1 && KC == 16 && MT == 4 && !CT)) return launch_conv_t<MT, KT, KC, CT, 3>(s, a, B);
         else return a.alpha ? launch_conv_t<MT, KT, KC, CT, 1>(s, a, B) : a.gelu ? launch_conv_t<MT, KT, KC, CT, 2>(s, a, B)
                                                                              : launch_conv_t<MT, KT, KC, CT, 0>(s, a, B);
     } else {
