@@ -84,7 +84,12 @@ __global__ void __launch_bounds__(256, (KC >= 32 && MT >= 3) ? 2 : (MT >= 4 ? 3 
     constexpr int TM = 32 * MT, TMP = voc_wpitch(TM), Q = KC / 4;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int halo = (KT - 1) * a.dil;
-    const int XW = VTN + halo;  // staged columns: l0-halo .. l0+127
+    // staged columns: l0-HA .. l0+127, HA = the halo rounded up to 4 columns, so that the tile starts on a 16-byte boundary of
+    // its row and is fetched as float4 groups (round 3: as 4-byte loads -- six per thread and stage, each with its own bounds
+    // logic and LDS store -- the input tile cost as much as the five times larger weight tile; timing with either staging
+    // compiled out)
+    const int HA = (halo + 3) & ~3;
+    const int XW = VTN + HA;
     const int XP = voc_xpitch(XW);     // their row pitch in LDS
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Ws = lds;                   // [KT][KC][TMP]
@@ -183,32 +188,40 @@ __global__ void __launch_bounds__(256, (KC >= 32 && MT >= 3) ? 2 : (MT >= 4 ? 3 
                     }
                 }
             } else {
-                constexpr int XJ = (VTN + (KT - 1) * 9 + LPC - 1) / LPC;   // dilation <= 9 (launcher)
-                constexpr int XB = XJ < 8 ? XJ : 8;                          // loads in flight per thread (register budget)
+                // float4 groups of the tile: (VTN + HA) / 4 per channel, dealt to the LPC lanes of the channel (dilation <= 9: launcher)
+                constexpr int XG = (VTN + (((KT - 1) * 9 + 3) & ~3)) / 4, XJ = (XG + LPC - 1) / LPC;
+                float4 xv[XJ];
 #pragma unroll
-                for (int j0 = 0; j0 < XJ; j0 += XB) {
-                    float xv[XB];
+                for (int j = 0; j < XJ; j++) {
+                    const int c4 = (xl + j * LPC) * 4;
+                    // a group is wholly left of column 0 or not at all (l0 - HA is a multiple of 4); its row is 16-byte aligned
+                    // (4 | ldx) and padded to the pitch, so a group that straddles Lin reads allocated columns
+                    const int l = l0 - HA + c4, lc = (c4 < XW && l >= 0 && l < a.Lin) ? l : 0;
+                    xv[j] = *(const float4*)(xb + (unsigned)((ci0 + xci) * a.ldx + lc));
+                }
+                store_w();
 #pragma unroll
-                    for (int j = 0; j < XB; j++) {
-                        const int col = xl + (j0 + j) * LPC;
-                        const int l = l0 - halo + col, lc = (col < XW && l >= 0 && l < a.Lin) ? l : 0;
-                        xv[j] = xb[(unsigned)((ci0 + xci) * a.ldx + lc)];
-                    }
-                    if (j0 == 0) store_w();
-#pragma unroll
-                    for (int j = 0; j < XB; j++) {
-                        const int col = xl + (j0 + j) * LPC;
-                        if (col < XW) {
-                            const int l = l0 - halo + col;
-                            float v = xv[j];
-                            if (ACT == 1 || (ACT == 3 && a.alpha)) {
-                                const float sn = __sinf(al * v);
-                                v = v + ib * (sn * sn);
-                            }
-                            if (ACT == 2 || (ACT == 3 && a.gelu)) v = gelu_erf(v);
-                            if (l < 0 || l >= a.Lin) v = 0.f;
-                            Xs[xci * XP + col] = v;
+                for (int j = 0; j < XJ; j++) {
+                    const int c4 = (xl + j * LPC) * 4;
+                    if (c4 < XW) {
+                        const int l = l0 - HA + c4;
+                        float4 v = xv[j];
+                        if (ACT == 1 || (ACT == 3 && a.alpha)) {
+                            float sn;
+                            sn = __sinf(al * v.x); v.x = v.x + ib * (sn * sn);
+                            sn = __sinf(al * v.y); v.y = v.y + ib * (sn * sn);
+                            sn = __sinf(al * v.z); v.z = v.z + ib * (sn * sn);
+                            sn = __sinf(al * v.w); v.w = v.w + ib * (sn * sn);
                         }
+                        if (ACT == 2 || (ACT == 3 && a.gelu)) {
+                            v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+                        }
+                        if (l < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (l >= a.Lin) v.x = 0.f;
+                        if (l + 1 >= a.Lin) v.y = 0.f;
+                        if (l + 2 >= a.Lin) v.z = 0.f;
+                        if (l + 3 >= a.Lin) v.w = 0.f;
+                        *(float4*)(Xs + xci * XP + c4) = v;
                     }
                 }
             }
@@ -227,7 +240,7 @@ __global__ void __launch_bounds__(256, (KC >= 32 && MT >= 3) ? 2 : (MT >= 4 ? 3 
             // another 10 % of the 7-tap and 20 % of the transposed convs.)
 #pragma unroll 1
             for (int k = 0; k < KT; k++) {
-                const int off = halo - (KT - 1 - k) * a.dil + w * 32 + (lane & 31);
+                const int off = HA - (KT - 1 - k) * a.dil + w * 32 + (lane & 31);
 #pragma unroll
                 for (int kk = 0; kk < KC; kk += 2) {
                     const int ci = kk + (lane >> 5);
@@ -324,7 +337,7 @@ static int launch_conv_t(hipStream_t s, const ConvArgs& a, int B) {
         Q3_LOG("voc conv: dilation %d > 9 is not built", a.dil);
         return -1;
     }
-    size_t lds = ((size_t)KT * KC * TMP + (size_t)KC * voc_xpitch(VTN + halo)) * sizeof(float);
+    size_t lds = ((size_t)KT * KC * TMP + (size_t)KC * voc_xpitch(VTN + ((halo + 3) & ~3))) * sizeof(float);
     if (CT && lds < (size_t)32 * (VTN + 1) * sizeof(float)) lds = (size_t)32 * (VTN + 1) * sizeof(float);   // store slab
     // experiment knob: Q3_VOC_LDS_PAD=bytes raises every conv launch's LDS request, i.e. lowers the vocoder's
     // residency per CU evenly (room for the frame loop's workgroups when the two run side by side)
@@ -508,7 +521,7 @@ template <int MT>
 __global__ void __launch_bounds__(256, MT <= 3 ? 3 : 2) resunit_kernel(ResUnitArgs a) {
     constexpr int C = 32 * MT, KT = 7, KC = 8, TMP = voc_wpitch(C);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int halo = (KT - 1) * a.dil, XW = VTN + halo, XP = voc_xpitch(XW);
+    const int halo = (KT - 1) * a.dil, HA = (halo + 3) & ~3, XW = VTN + HA, XP = voc_xpitch(XW);   // (conv_kernel: float4 staging)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Ws = lds;                   // [KT][KC][TMP]; later one row tile of the 1x1 weights [C/2][64]
     float* Xs = lds + KT * KC * TMP;   // [KC][XP]
@@ -540,15 +553,15 @@ __global__ void __launch_bounds__(256, MT <= 3 ? 3 : 2) resunit_kernel(ResUnitAr
                 const int cg = ci0 + ci;
                 wv[i] = *(const float4*)(a.w7 + (unsigned)((((cg >> 3) * KT + k) * 8 + (cg & 7)) * C + m4 * 4));
             }
-            constexpr int LPC = 256 / KC, XJ = (VTN + (KT - 1) * 9 + LPC - 1) / LPC;
+            constexpr int LPC = 256 / KC, XG = (VTN + (((KT - 1) * 9 + 3) & ~3)) / 4, XJ = (XG + LPC - 1) / LPC;
             const int xci = tid / LPC, xl = tid - xci * LPC;
             const float al = a.al7[ci0 + xci], ib = a.ib7[ci0 + xci];
-            float xv[XJ];
+            float4 xv[XJ];
 #pragma unroll
             for (int j = 0; j < XJ; j++) {
-                const int col = xl + j * LPC;
-                const int l = l0 - halo + col, lc = (col < XW && l >= 0 && l < a.Lin) ? l : 0;
-                xv[j] = xb[(unsigned)((ci0 + xci) * a.ld + lc)];
+                const int c4 = (xl + j * LPC) * 4;
+                const int l = l0 - HA + c4, lc = (c4 < XW && l >= 0 && l < a.Lin) ? l : 0;
+                xv[j] = *(const float4*)(xb + (unsigned)((ci0 + xci) * a.ld + lc));
             }
 #pragma unroll
             for (int i = 0; i < WIT; i++) {
@@ -560,19 +573,27 @@ __global__ void __launch_bounds__(256, MT <= 3 ? 3 : 2) resunit_kernel(ResUnitAr
             }
 #pragma unroll
             for (int j = 0; j < XJ; j++) {
-                const int col = xl + j * LPC;
-                if (col < XW) {
-                    const int l = l0 - halo + col;
-                    const float sn = __sinf(al * xv[j]);
-                    float v = xv[j] + ib * (sn * sn);
-                    if (l < 0 || l >= a.Lin) v = 0.f;
-                    Xs[xci * XP + col] = v;
+                const int c4 = (xl + j * LPC) * 4;
+                if (c4 < XW) {
+                    const int l = l0 - HA + c4;
+                    float4 v = xv[j];
+                    float sn;
+                    sn = __sinf(al * v.x); v.x = v.x + ib * (sn * sn);
+                    sn = __sinf(al * v.y); v.y = v.y + ib * (sn * sn);
+                    sn = __sinf(al * v.z); v.z = v.z + ib * (sn * sn);
+                    sn = __sinf(al * v.w); v.w = v.w + ib * (sn * sn);
+                    if (l < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (l >= a.Lin) v.x = 0.f;
+                    if (l + 1 >= a.Lin) v.y = 0.f;
+                    if (l + 2 >= a.Lin) v.z = 0.f;
+                    if (l + 3 >= a.Lin) v.w = 0.f;
+                    *(float4*)(Xs + xci * XP + c4) = v;
                 }
             }
             __syncthreads();
 #pragma unroll 1
             for (int k = 0; k < KT; k++) {
-                const int off = halo - (KT - 1 - k) * a.dil + w * 32 + (lane & 31);
+                const int off = HA - (KT - 1 - k) * a.dil + w * 32 + (lane & 31);
 #pragma unroll
                 for (int kk = 0; kk < KC; kk += 2) {
                     const int ci = kk + (lane >> 5);
@@ -643,7 +664,7 @@ static int launch_resunit_t(hipStream_t s, ResUnitArgs a, int B) {
     constexpr int C = 32 * MT;
     const int halo = 6 * a.dil;
     if (a.dil > 9) return -1;
-    const size_t lds = ((size_t)7 * 8 * voc_wpitch(C) + (size_t)8 * voc_xpitch(VTN + halo) + 4 * C) * sizeof(float);
+    const size_t lds = ((size_t)7 * 8 * voc_wpitch(C) + (size_t)8 * voc_xpitch(VTN + ((halo + 3) & ~3)) + 4 * C) * sizeof(float);
     a.tiles_l = (a.Lin + VTN - 1) / VTN;
     a.n_tiles = a.tiles_l * B;
     int grid = a.n_tiles;
