@@ -46,7 +46,10 @@ int voc_decode(void* v, const int64_t* codes, int B, float* out);
 
 /* VocoderServer.synthesize + int16 conversion for one utterance: codes[n][16] -> out samples.
  * out must hold voc_synthesize_max_samples(n) int16.  Returns 0 and *n_samples, or <0.
- * (n > chunk_tokens walks chunks with a 16-frame overlap: needs chunk_tokens > 32.) */
+ * (n > chunk_tokens walks chunks with a 16-frame overlap: needs chunk_tokens > 32.)
+ * A chunk of fewer than chunk_tokens frames (an utterance's tail, or a short utterance) is decoded at its own length + 1
+ * pad frame, rounded up to 8, instead of the reference's zero-padded chunk_tokens: the decoder is causal but for a quarter
+ * frame of look-ahead, so the samples the walk keeps are bit-identical (env Q3_VOC_FULL_CHUNKS=1: pad as the reference). */
 int voc_synthesize(void* v, const int64_t* codes, int n_tokens, int16_t* out, int32_t* n_samples);
 /* same, float output before the int16 rule */
 int voc_synthesize_f32(void* v, const int64_t* codes, int n_tokens, float* out, int32_t* n_samples);

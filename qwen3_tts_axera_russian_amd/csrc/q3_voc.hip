@@ -16,6 +16,7 @@
 #include "../../include/qwen3tts_voc.h"
 #include "q3_common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <utility>
 
@@ -48,6 +49,9 @@ struct ConvArgs {
     // (lt samples trimmed on the left), kept when 0 <= that < Lout; Lc = columns of the polyphase GEMM that reach a
     // kept output (= Lin for the trims in use; inputs at l >= Lin read as zero)
     int lt = 0, Lout = 0, Lc = 0;
+    // Lc of this op when the decode runs the full chunk length: the launcher's variant rule looks at it, so that a decode of
+    // fewer frames (voc_run's T) sums every column in the same order as the full-length one (0: use Lc)
+    int Lrule = 0;
     int n_tiles = 0, tiles_l = 0, tiles_m = 0;  // set by the launcher
     // one-tap, stride-1 convs (pointwise projections): the columns of all B chunks form ONE axis of B*Lin columns
     // (a column needs no neighbour), so 128-column tiles stay full when a chunk is only 64 columns long
@@ -480,7 +484,7 @@ static int launch_conv(hipStream_t s, const ConvArgs& a, int B) {
     static const int kc_max = getenv("Q3_VOC_KC_MAX") ? atoi(getenv("Q3_VOC_KC_MAX")) : 16;
     // (the rule looks at ONE chunk's columns, never at the batch: a chunk must decode to the same bits alone and inside a
     // batch, and with two taps the stage width changes the order in which taps and channels are summed)
-    const bool short_act = a.Lc <= 512 && a.M <= 4096 && c % 32 == 0 && a.K <= 2;   // (not the 1536 -> 768 x 8 transposed conv: 2.92 -> 3.10 ms)
+    const bool short_act = (a.Lrule > 0 ? a.Lrule : a.Lc) <= 512 && a.M <= 4096 && c % 32 == 0 && a.K <= 2;   // (not the 1536 -> 768 x 8 transposed conv: 2.92 -> 3.10 ms)
     if (kc_max < 32 && !short_act && c % 16 == 0 && (a.K == 1 || a.K == 2))
         return a.K == 1 ? launch_conv_mt<1, 16>(s, a, B) : launch_conv_mt<2, 16>(s, a, B);
     switch (a.K) {
@@ -1810,12 +1814,18 @@ static int voc_conv_split(Voc* v, const VocOp& op, const VocOp* next, bool last,
     return 0;
 }
 
+// T: frames per chunk of THIS decode (0 = the model's chunk length).  Every op is causal per column apart from the
+// transposed convs' look-ahead of one input column (< 1 frame in total), so the first n frames' samples of a decode of
+// T > n frames are the same bits whatever T is: the chunk walk decodes a short tail chunk at its own length + 1 pad frame
+// instead of the reference's zero-padded 64 (d_codes then holds [B][T][16]).
 static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = nullptr, long* outL = nullptr,
-                   float* op_ms = nullptr, bool force_exact = false) {
+                   float* op_ms = nullptr, bool force_exact = false, int T = 0) {
     // ping-pong between buf[0]/buf[1]; buf[2] keeps the residual-unit input (exact path)
     int cur = 0;
     int C = 0;
-    long L = v->chunk;
+    if (T <= 0 || T > v->chunk) T = v->chunk;
+    long L = T;
+    long Lf = v->chunk;   // the same op's length in a full-length decode (variant rules look at it)
     float* res = nullptr;
     SplitState st;
     const size_t nrun = n_ops < 0 ? v->ops.size() : (size_t)n_ops < v->ops.size() ? (size_t)n_ops : v->ops.size();
@@ -1827,10 +1837,10 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
         const int ld = (int)pitch4(L);
         if (op.op == VOP_RVQ || op.op == VOP_EMBMEAN) {
             if (op.op == VOP_RVQ)
-                hipLaunchKernelGGL(rvq_kernel, dim3(v->chunk, B), dim3(256), 2 * op.cin * sizeof(float), v->s, v->d_codes, op.w,
-                                   op.p_sem, op.p_ac, out, v->chunk, ld, op.nq, op.cb, op.cin, op.cout);
+                hipLaunchKernelGGL(rvq_kernel, dim3(T, B), dim3(256), 2 * op.cin * sizeof(float), v->s, v->d_codes, op.w,
+                                   op.p_sem, op.p_ac, out, T, ld, op.nq, op.cb, op.cin, op.cout);
             else
-                hipLaunchKernelGGL(embmean_kernel, dim3(v->chunk, B), dim3(256), 0, v->s, v->d_codes, op.w, out, v->chunk, ld,
+                hipLaunchKernelGGL(embmean_kernel, dim3(T, B), dim3(256), 0, v->s, v->d_codes, op.w, out, T, ld,
                                    op.nq, 16, op.cb, op.cout);
             Q3_HIP(hipGetLastError(), -1);
             C = op.cout;
@@ -1888,7 +1898,7 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
             }
             cur = st.f32_idx;
             C = op.cout;
-            if (op.op == VOP_CONVT) L = convt_out(op, L);
+            if (op.op == VOP_CONVT) L = convt_out(op, L), Lf = convt_out(op, Lf);
         } else if (g_voc_fuse && op.op == VOP_CONV && op.k == 7 && (op.flags & VF_RES_SAVE) && (op.flags & VF_SNAKE) &&
                    op.cin == op.cout && resunit_channels(op.cin) && i + 1 < nrun && v->ops[i + 1].w1p && st.f32_cur) {
             // a whole residual unit (this 7-tap conv + the 1x1 conv that closes it) in one launch
@@ -1945,6 +1955,7 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
                 a.stride = 1;
                 a.M = op.cout;
                 a.Lout = a.Lc = (int)L;
+                a.Lrule = (int)Lf;
             } else {
                 a.K = op.k / op.p0;
                 a.dil = 1;
@@ -1953,6 +1964,7 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
                 a.lt = op.lt;
                 a.Lout = (int)convt_out(op, L);
                 a.Lc = (int)convt_cols(op, L);
+                a.Lrule = (int)convt_cols(op, Lf);
             }
             a.ldy = (int)pitch4(a.Lout);
             if (op.flags & VF_RES_SAVE) {
@@ -1964,7 +1976,7 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
             if (op.flags & VF_RES_ADD) a.res = res ? res : st.res;
             if (launch_conv(v->s, a, B)) return -1;
             C = op.cout;
-            if (op.op == VOP_CONVT) L = convt_out(op, L);
+            if (op.op == VOP_CONVT) L = convt_out(op, L), Lf = convt_out(op, Lf);
             cur ^= 1;
             st.f32_idx = cur;
             st.f32_cur = true;
@@ -2037,6 +2049,18 @@ int voc_debug_run(void* vv, const int64_t* codes, int B, int n_ops, float* out, 
     return 0;
 }
 
+// Frames a chunk of `len` real frames is decoded at: its own length plus the one pad frame the transposed convs' look-ahead
+// reaches into (voc_run's note), rounded up to 8 so that a request's tail chunks fall into few groups; the full chunk for a
+// full chunk, under the split-f16 arithmetic (its overflow redo is per call) and with Q3_VOC_FULL_CHUNKS=1 (A/B knob).
+static int voc_decode_frames(const Voc* v, int len) {
+    static const int full = getenv("Q3_VOC_FULL_CHUNKS") ? atoi(getenv("Q3_VOC_FULL_CHUNKS")) : 0;
+    static const int rnd = getenv("Q3_VOC_FRAME_ROUND") ? atoi(getenv("Q3_VOC_FRAME_ROUND")) : 8;
+    if (full || g_voc_split || len >= v->chunk) return v->chunk;
+    const int r = rnd > 0 ? rnd : 1;
+    const int t = (len + 1 + r - 1) / r * r;
+    return t < v->chunk ? t : v->chunk;
+}
+
 int voc_synthesize_max_samples(void* vv, int n) {
     Voc* v = (Voc*)vv;
     if (!v || n <= 0) return 0;
@@ -2064,7 +2088,23 @@ int voc_synthesize_f32(void* vv, const int64_t* codes, int n, float* out, int32_
     auto run_chunk = [&](int start, int len) -> int {
         std::fill(padded.begin(), padded.end(), 0);
         memcpy(padded.data(), codes + (size_t)start * 16, sizeof(int64_t) * 16 * len);
-        return voc_decode(v, padded.data(), 1, chunk.data());
+        const int T = voc_decode_frames(v, len);
+        if (T == CH) return voc_decode(v, padded.data(), 1, chunk.data());
+        // a short chunk: decoded at T frames (same bits for the samples the walk keeps), only those samples come back
+        Q3_HIP(hipMemcpyAsync(v->d_codes, padded.data(), sizeof(int64_t) * 16 * (size_t)T, hipMemcpyHostToDevice, v->s), -1);
+        Q3_HIP(hipEventRecord(v->e0, v->s), -1);
+        float* res = nullptr;
+        long LL = 0;
+        if (voc_run(v, 1, &res, -1, nullptr, &LL, nullptr, false, T)) return -1;
+        Q3_HIP(hipEventRecord(v->e1, v->s), -1);
+        if ((size_t)LL < sliced(len)) {
+            Q3_LOG("voc_synthesize: a decode of %d frames yields %ld samples, fewer than the %zu kept", T, LL, sliced(len));
+            return -1;
+        }
+        Q3_HIP(hipMemcpyAsync(chunk.data(), res, sizeof(float) * sliced(len), hipMemcpyDeviceToHost, v->s), -1);
+        Q3_HIP(hipStreamSynchronize(v->s), -1);
+        hipEventElapsedTime(&v->last_ms, v->e0, v->e1);
+        return 0;
     };
     if (n <= CH) {
         if (run_chunk(0, n)) return -1;
@@ -2170,28 +2210,42 @@ int synth_batch(Voc* v, const int64_t* codes, const int32_t* n_tokens, int U, in
         Q3_HIP(hipMalloc((void**)&v->d_wave, sizeof(float) * (size_t)total), -1);
         v->wave_cap = (size_t)total;
     }
-    const int pitch = (int)pitch4(v->chunk_samples), OV = 16 * v->upsample;
+    const int OV = 16 * v->upsample;
+    // chunks of one decode length run together: full chunks first, then the tail chunks by length (voc_decode_frames)
+    std::vector<int> order(walk.size()), frames(walk.size());
+    for (size_t i = 0; i < walk.size(); i++) order[i] = (int)i, frames[i] = voc_decode_frames(v, walk[i].len);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return frames[x] > frames[y]; });
     std::vector<int64_t> padded((size_t)v->max_batch * CH * 16);
     std::vector<ChunkPlace> place(v->max_batch);
     bool redo_exact = false;
     for (int attempt = 0; attempt < 2; attempt++) {
         Q3_HIP(hipEventRecord(v->e0, v->s), -1);
-        for (size_t c0 = 0; c0 < walk.size(); c0 += v->max_batch) {
-            const int B = (int)((walk.size() - c0 < (size_t)v->max_batch) ? walk.size() - c0 : v->max_batch);
-            std::fill(padded.begin(), padded.begin() + (size_t)B * CH * 16, 0);
+        for (size_t c0 = 0; c0 < walk.size();) {
+            const int T = frames[order[c0]];
+            int B = 0;
+            while (c0 + B < walk.size() && B < v->max_batch && frames[order[c0 + B]] == T) B++;
+            std::fill(padded.begin(), padded.begin() + (size_t)B * T * 16, 0);
             for (int b = 0; b < B; b++) {
-                const WalkChunk& w = walk[c0 + b];
-                memcpy(padded.data() + (size_t)b * CH * 16, codes + code_off[w.utt] + (size_t)w.start * 16, sizeof(int64_t) * 16 * w.len);
+                const WalkChunk& w = walk[order[c0 + b]];
+                memcpy(padded.data() + (size_t)b * T * 16, codes + code_off[w.utt] + (size_t)w.start * 16, sizeof(int64_t) * 16 * w.len);
                 place[b] = {b, (int)w.cl, w.head, w.dst};
             }
-            Q3_HIP(hipMemcpyAsync(v->d_codes, padded.data(), sizeof(int64_t) * 16 * (size_t)CH * B, hipMemcpyHostToDevice, v->s), -1);
+            Q3_HIP(hipMemcpyAsync(v->d_codes, padded.data(), sizeof(int64_t) * 16 * (size_t)T * B, hipMemcpyHostToDevice, v->s), -1);
             Q3_HIP(hipMemcpyAsync(v->d_place, place.data(), sizeof(ChunkPlace) * B, hipMemcpyHostToDevice, v->s), -1);
             float* res = nullptr;
-            if (voc_run(v, B, &res, -1, nullptr, nullptr, nullptr, redo_exact)) return -1;
+            long LL = 0;
+            if (voc_run(v, B, &res, -1, nullptr, &LL, nullptr, redo_exact, T)) return -1;
+            for (int b = 0; b < B; b++)
+                if ((long)place[b].len > LL) {
+                    Q3_LOG("voc_synthesize_batch: a decode of %d frames yields %ld samples, fewer than the %d kept", T, LL, place[b].len);
+                    return -1;
+                }
+            const int pitch = (int)pitch4(LL);
             hipLaunchKernelGGL(voc_place_copy_kernel, dim3(64, B), dim3(256), 0, v->s, res, pitch, v->d_place, v->d_wave);
             hipLaunchKernelGGL(voc_place_blend_kernel, dim3(32, B), dim3(256), 0, v->s, res, pitch, v->d_place, v->d_wave, OV);
             Q3_HIP(hipGetLastError(), -1);
             Q3_HIP(hipStreamSynchronize(v->s), -1);   // the staging vectors are reused by the next batch
+            c0 += B;
         }
         Q3_HIP(hipEventRecord(v->e1, v->s), -1);
         int ovf = 0;

@@ -216,6 +216,36 @@ def test_full_size_table_is_causal_and_deterministic(gpu_lib, tmp_path_factory):
     v.close()
 
 
+def test_short_chunks_decode_at_their_own_length_to_the_same_bits(gpu_lib):
+    """The chunk walk decodes a chunk of n < 64 frames at n + 1 frames rounded up to 8 (voc_decode_frames) instead of the
+    reference's zero-padded 64 (vocoder_server.py:78-81): the decoder is causal but for a quarter frame of look-ahead,
+    so the samples the walk keeps (n * 1920) must be the SAME BITS as the padded 64-frame decode's -- at the full-size
+    table, where the shorter activations would otherwise pick other kernel variants (other summation orders), for the
+    single-utterance entry point and for the batched one (chunks of one decode length share a launch)."""
+    path = os.path.join(CACHE, "voc_whole_s1234.q3w")
+    if not os.path.exists(path):
+        W.write_pack(path, {"voc_chunk": 64.0}, W.make_synthetic_voc(W.VocConfig(), seed=1234))
+    v = Voc(gpu_lib, path, max_batch=4)
+    rng = np.random.default_rng(17)
+    lens = [1, 6, 7, 8, 20, 33, 47, 55, 56, 63, 64, 70]
+    utts = [rng.integers(0, 2048, size=(n, 16)).astype(np.int64) for n in lens]
+    want = [fe.voc_synthesize(c, lambda padded: v.decode(padded)[0], 64) for c in utts]
+    for c, w in zip(utts, want):
+        np.testing.assert_array_equal(v.synth_f32(c), w)
+    nn = np.array(lens, np.int32)
+    cat = np.ascontiguousarray(np.concatenate(utts, axis=0))
+    cap = int(gpu_lib.voc_synthesize_batch_max_samples(v.h, hiplib.iptr(nn), len(nn)))
+    out = np.empty(cap, np.float32)
+    off = np.zeros(len(lens) + 1, np.int64)
+    assert gpu_lib.voc_synthesize_batch_f32(v.h, cat.ctypes.data_as(hiplib.i64p), hiplib.iptr(nn), len(nn), hiplib.fptr(out), cap,
+                                            off.ctypes.data_as(hiplib.i64p)) == 0
+    short_ms = float(gpu_lib.voc_last_batch_ms(v.h))
+    for u, w in enumerate(want):
+        np.testing.assert_array_equal(out[off[u]:off[u + 1]], w)
+    v.close()
+    print("12 utterances (13 chunks, 450 frames) at their own lengths:", short_ms, "ms")
+
+
 def test_full_size_table_matches_torch_reference_in_both_arithmetic_modes(gpu_lib):
     """Numerics (not only properties) at the FULL default table -- the vocoder the benchmark times, with its
     96-row / 128- and 256-column tiles, XCD tile order and every kernel variant of the 1536 -> 96 channel trunk:
