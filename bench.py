@@ -112,16 +112,24 @@ def deal(n_text_all, world):
     return [order[r::world] for r in range(world)]
 
 
+def workload_indices(B, rank, world=1):
+    """Job-wide indices (0 .. world*B-1) of the utterances in this rank's slots, in slot order."""
+    return deal([PROMPT_TOKENS[i % len(PROMPT_TOKENS)] for i in range(world * B)], world)[rank]
+
+
 def workload(B, rank, seed, world=1):
     """This rank's B utterances of the job's world*B (the fixed prompt set, repeated): prefix rows = n_text + 9
-    (llamacpp_talker_server.py:121-161).  Every utterance has its own seeded embeddings, whatever rank runs it."""
+    (llamacpp_talker_server.py:121-161).  The job is the prompt set repeated (BASELINE configs[3]: 256 = the 32 prompts x 8):
+    utterance i carries prompt i % 32 -- its length and its seeded embeddings -- whatever rank runs it, and the pad embedding
+    is one vector for the job (tts_pad_embed is a model constant, llamacpp_talker_server.py:88-93), so a prompt's trajectory
+    does not depend on the number of ranks or on the rank and slot it is dealt to (what the result check relies on)."""
     total = world * B
     n_text_all = [PROMPT_TOKENS[i % len(PROMPT_TOKENS)] for i in range(total)]
-    mine = deal(n_text_all, world)[rank]
+    mine = workload_indices(B, rank, world)
     n_text = [n_text_all[i] for i in mine]
-    prefixes = [(0.03 * np.random.default_rng(seed + 7919 * i).standard_normal((n_text_all[i] + 9, 1024))).astype(np.float32)
+    prefixes = [(0.03 * np.random.default_rng(seed + 7919 * (i % len(PROMPT_TOKENS))).standard_normal((n_text_all[i] + 9, 1024))).astype(np.float32)
                 for i in mine]
-    pad = (0.03 * np.random.default_rng(seed + 1000 * rank).standard_normal(1024)).astype(np.float32)
+    pad = (0.03 * np.random.default_rng(seed).standard_normal(1024)).astype(np.float32)
     return prefixes, n_text, pad
 
 
@@ -238,28 +246,14 @@ def verify_first_utterance(codes_f16, seed, frames=64):
             "oracle_gap_at_the_divergence": round(gap, 6)}
 
 
-def verify_against_fixture(codes, B, F, seed, world, prefixes, n_text, pad):
-    """Result check of the benchmark itself (the reference's client reports RTF for audio it really wrote,
-    tts_client.py:268-271): the codec ids of the last TIMED step against the committed CPU-oracle trajectory of this
-    exact workload (tests/golden/bench_b32_f64.npz, made by tests/golden/make_bench_golden.py) -- a data file, nothing
-    under oracle/ is imported.  Free-running greedy streams of two float pipelines are identical up to a decision whose
-    oracle top-1/top-2 gap is a float near-tie (< NEAR_TIE); anything else fails the benchmark."""
-    import hashlib
-    fx = os.path.join(ROOT, "tests", "golden", "bench_b32_f64.npz")
-    if world != 1 or not os.path.exists(fx):
-        return {"checked": False, "why": "the fixture covers the single-GPU workload (bench.workload(32, 0, 1234))"}
-    g = np.load(fx)
-    ids, margins = g["ids"].astype(np.int32), g["margins"].astype(np.float32)
-    h = hashlib.sha256()
-    for p_ in prefixes:
-        h.update(np.ascontiguousarray(p_).tobytes())
-    h.update(np.asarray(n_text, np.int32).tobytes())
-    h.update(np.ascontiguousarray(pad).tobytes())
-    if (B, F, seed) != (ids.shape[0], ids.shape[1], int(g["seed"])) or h.hexdigest() != bytes(g["inputs_sha"]).decode():
-        return {"checked": False, "why": f"fixture is for batch {ids.shape[0]} x {ids.shape[1]} frames, seed {int(g['seed'])}"}
+def grade_slots(codes, F, slot_to_fixture, ids, margins):
+    """Grade this rank's slots that the fixture covers: slot s against ids[slot_to_fixture[s]].  Free-running greedy
+    streams of two float pipelines are identical up to a decision whose oracle top-1/top-2 gap is a float near-tie
+    (< NEAR_TIE).  -> (leading identical frames per graded slot, decisions that diverge at no near-tie, largest gap at a
+    divergence)."""
     lead, bad, worst = [], [], 0.0
-    for b in range(B):
-        eq = (codes[:F, b, :] == ids[b])
+    for s_, b in sorted(slot_to_fixture.items()):
+        eq = (codes[:F, s_, :] == ids[b])
         if eq.all():
             lead.append(F)
             continue
@@ -269,16 +263,67 @@ def verify_against_fixture(codes, B, F, seed, world, prefixes, n_text, pad):
         worst = max(worst, gap)
         lead.append(f)
         if not gap < NEAR_TIE:
-            bad.append((b, f, gidx, gap))
-    res = {"checked": True, "fixture": "tests/golden/bench_b32_f64.npz (CPU oracle, same weights and prompts)",
-           "utterances": B, "frames": F, "rule": f"identical ids up to a decision whose oracle top-1/top-2 gap < {NEAR_TIE}",
-           "ok": not bad, "utterances_identical_over_all_frames": int(sum(x == F for x in lead)),
-           "identical_leading_frames": {"min": int(min(lead)), "median": int(np.median(lead)), "total": int(sum(lead)),
-                                        "of": B * F},
+            bad.append((s_, f, gidx, gap))
+    return lead, bad, worst
+
+
+def fixture_slots(B, rank, world, n_fixture):
+    """slot -> fixture row for this rank: the fixture holds the prompt set (n_fixture prompts) in the slot order of the
+    single-GPU run (bench.workload(n_fixture, 0, seed)); utterance i of a larger job is prompt i % n_fixture."""
+    if n_fixture != len(PROMPT_TOKENS):
+        return {}
+    row_of = {i: b for b, i in enumerate(workload_indices(n_fixture, 0, 1))}
+    return {s_: row_of[i % n_fixture] for s_, i in enumerate(workload_indices(B, rank, world))}
+
+
+def verify_against_fixture(codes, B, F, seed, world, prefixes, n_text, pad, rank=0, ranks=None):
+    """Result check of the benchmark itself (the reference's client reports RTF for audio it really wrote,
+    tts_client.py:268-271): the codec ids of the last TIMED step against the committed CPU-oracle trajectory of this
+    exact workload (tests/golden/bench_b32_f64.npz, made by tests/golden/make_bench_golden.py) -- a data file, nothing
+    under oracle/ is imported.  The fixture holds the 32 prompts; a job of N ranks is that set N times (a prompt's
+    trajectory does not depend on its slot, its neighbours or its rank), every rank grades its 32 utterances and the counts
+    are summed over the ranks (utterances = 32 N).  Anything but a near-tie fails the benchmark."""
+    import hashlib
+    fx = os.path.join(ROOT, "tests", "golden", "bench_b32_f64.npz")
+    if not os.path.exists(fx):
+        return {"checked": False, "why": "tests/golden/bench_b32_f64.npz is missing"}
+    g = np.load(fx)
+    ids, margins = g["ids"].astype(np.int32), g["margins"].astype(np.float32)
+    NB = ids.shape[0]
+    # the fixture's own inputs, regenerated: guards the workload function, then this rank's rows against them
+    fp, fn, fpad = workload(NB, 0, int(g["seed"]), 1)
+    h = hashlib.sha256()
+    for p_ in fp:
+        h.update(np.ascontiguousarray(p_).tobytes())
+    h.update(np.asarray(fn, np.int32).tobytes())
+    h.update(np.ascontiguousarray(fpad).tobytes())
+    if (B, F, seed) != (NB, ids.shape[1], int(g["seed"])) or h.hexdigest() != bytes(g["inputs_sha"]).decode():
+        return {"checked": False, "why": f"fixture is for batch {NB} x {ids.shape[1]} frames, seed {int(g['seed'])}"}
+    slots = fixture_slots(B, rank, world, NB)
+    same_inputs = np.array_equal(pad, fpad) and all(np.array_equal(prefixes[s_], fp[b]) and n_text[s_] == fn[b]
+                                                    for s_, b in slots.items())
+    lead, bad, worst = grade_slots(codes, F, slots, ids, margins) if same_inputs else ([], [], 0.0)
+    tot = np.array([len(lead), sum(x == F for x in lead), sum(lead), len(bad), 0 if same_inputs else 1], np.float64)
+    lead_min = float(min(lead)) if lead else float(F)
+    if ranks is not None and world > 1:
+        tot = ranks.sum_over_ranks(tot)
+        worst = ranks.max_over_ranks(worst)
+        lead_min = -ranks.max_over_ranks(-lead_min)
+    n = int(tot[0])
+    res = {"checked": n > 0 and tot[4] == 0, "fixture": "tests/golden/bench_b32_f64.npz (CPU oracle, same weights and prompts)",
+           "utterances": n, "frames": F, "rule": f"identical ids up to a decision whose oracle top-1/top-2 gap < {NEAR_TIE}",
+           "ok": n > 0 and tot[3] == 0 and tot[4] == 0, "utterances_identical_over_all_frames": int(tot[1]),
+           "identical_leading_frames": {"min": int(lead_min), "total": int(tot[2]), "of": n * F},
            "largest_oracle_gap_at_a_divergence": round(worst, 6)}
+    if world == 1:
+        res["identical_leading_frames"]["median"] = int(np.median(lead)) if lead else 0
+    else:
+        res["graded_over_ranks"] = world
+    if tot[4]:
+        res["why"] = "a rank's inputs differ from the fixture's"
     if bad:
-        print(f"[bench] RESULT CHECK FAILED: codes diverge from the oracle at decisions that are no near-ties: {bad[:5]}",
-              file=sys.stderr, flush=True)
+        print(f"[bench] RESULT CHECK FAILED (rank {rank}): codes diverge from the oracle at decisions that are no near-ties: "
+              f"{bad[:5]}", file=sys.stderr, flush=True)
     return res
 
 
@@ -534,6 +579,15 @@ class Ranks:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def sum_over_ranks(self, x):
+        """Element-wise sum of a small float64 vector over the ranks."""
+        if self.dist is None:
+            return np.asarray(x, np.float64)
+        import torch
+        t = torch.tensor(np.asarray(x, np.float64), dtype=torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
     def close(self):
         if self.dist is not None:
             self.dist.destroy_process_group()
@@ -609,7 +663,7 @@ def main():
         # (fp32-grade against float64) is reported beside it as an option
         lib.voc_set_exact_fp32(1)
     dt, frame_ms_step, prefill_ms, voc_ms = run_leg(eng, voc, prefixes, n_text, pad, F, a.steps, a.warmup, sync_all)
-    verified = verify_against_fixture(run_leg.last_codes, B, F, a.seed, world, prefixes, n_text, pad)
+    verified = verify_against_fixture(run_leg.last_codes, B, F, a.seed, world, prefixes, n_text, pad, rank, R)
     # the frame graph alone on the chip (inside a step the previous step's vocoder chunk runs beside it and the two
     # split the machine: the step time is their sum either way, the kernel-quality figure is this one)
     eng.start(prefixes, n_text, ignore_eos=True, max_frames=F)

@@ -84,3 +84,69 @@ def test_bench_gpus_2_starts_two_ranks_itself():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub-engine", "--backend", "gloo"],
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0
+
+
+def test_every_rank_runs_the_fixture_prompts_whatever_the_rank_count():
+    """The result check at N ranks: the job is the 32-prompt set N times (BASELINE configs[3]), utterance i = prompt i % 32
+    with that prompt's inputs, so every slot of every rank has a fixture row and each rank holds every prompt once."""
+    sys.path.insert(0, ROOT)
+    import bench
+    row_of = {i: b for b, i in enumerate(bench.workload_indices(32, 0, 1))}
+    assert sorted(row_of) == list(range(32)) and bench.fixture_slots(32, 0, 1, 32) == {s: s for s in range(32)}
+    p1, n1, pad1 = bench.workload(32, 0, 1234, 1)
+    for world in (2, 4, 8):
+        for rank in (0, world - 1):
+            mine = bench.workload_indices(32, rank, world)
+            slots = bench.fixture_slots(32, rank, world, 32)
+            assert sorted(slots) == list(range(32)) and sorted(slots.values()) == list(range(32))
+            assert all(row == row_of[mine[slot] % 32] for slot, row in slots.items())
+            pw, nw, padw = bench.workload(32, rank, 1234, world)
+            assert (pad1 == padw).all()
+            for slot, row in slots.items():
+                assert nw[slot] == n1[row] and (pw[slot] == p1[row]).all()
+
+
+def _verify_worker(rank, world, port, q, spoil):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import bench
+    R = bench.Ranks("gloo")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "bench_b32_f64.npz"))
+    ids = g["ids"].astype(np.int32)
+    prefixes, n_text, pad = bench.workload(32, rank, 1234, world)
+    codes = np.full((64, 32, 16), 5, np.int32)                    # slots the fixture does not cover: anything
+    for slot, row in bench.fixture_slots(32, rank, world, 32).items():
+        codes[:, slot, :] = ids[row]
+    if spoil and rank == 1:                                       # one decision of one graded utterance, where the oracle's gap is wide
+        slot, row = sorted(bench.fixture_slots(32, rank, world, 32).items())[0]
+        m = g["margins"].astype(np.float32)[row]
+        f, k = np.unravel_index(int(np.argmax(m)), m.shape)
+        codes[f, slot, k] = (codes[f, slot, k] + 1) % 2048
+    q.put((rank, bench.verify_against_fixture(codes, 32, 64, 1234, world, prefixes, n_text, pad, rank, R)))
+    R.close()
+
+
+def test_result_check_is_summed_over_two_ranks():
+    """Both ranks report the same verdict: 64 utterances graded in all (the prompt set on either rank), all identical; one
+    wrong id at a decision that is no near-tie on rank 1 fails the check on every rank."""
+    ctx = mp.get_context("spawn")
+    for spoil in (False, True):
+        q = ctx.Queue()
+        port = 31500 + os.getpid() % 2000 + int(spoil)
+        procs = [ctx.Process(target=_verify_worker, args=(r, 2, port, q, spoil)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = dict(q.get(timeout=180) for _ in range(2))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert res[0] == res[1]
+        v = res[0]
+        assert v["checked"] and v["utterances"] == 64 and v["graded_over_ranks"] == 2
+        if spoil:
+            assert not v["ok"] and v["utterances_identical_over_all_frames"] == 63
+        else:
+            assert v["ok"] and v["utterances_identical_over_all_frames"] == 64
+            assert v["identical_leading_frames"] == {"min": 64, "total": 4096, "of": 4096}
