@@ -310,9 +310,9 @@ def verify_against_fixture(codes, B, F, seed, world, prefixes, n_text, pad, rank
         worst = ranks.max_over_ranks(worst)
         lead_min = -ranks.max_over_ranks(-lead_min)
     n = int(tot[0])
-    res = {"checked": n > 0 and tot[4] == 0, "fixture": "tests/golden/bench_b32_f64.npz (CPU oracle, same weights and prompts)",
+    res = {"checked": bool(n > 0 and tot[4] == 0), "fixture": "tests/golden/bench_b32_f64.npz (CPU oracle, same weights and prompts)",
            "utterances": n, "frames": F, "rule": f"identical ids up to a decision whose oracle top-1/top-2 gap < {NEAR_TIE}",
-           "ok": n > 0 and tot[3] == 0 and tot[4] == 0, "utterances_identical_over_all_frames": int(tot[1]),
+           "ok": bool(n > 0 and tot[3] == 0 and tot[4] == 0), "utterances_identical_over_all_frames": int(tot[1]),
            "identical_leading_frames": {"min": int(lead_min), "total": int(tot[2]), "of": n * F},
            "largest_oracle_gap_at_a_divergence": round(worst, 6)}
     if world == 1:

@@ -143,10 +143,26 @@ def test_result_check_is_summed_over_two_ranks():
             p.join(timeout=60)
             assert p.exitcode == 0
         assert res[0] == res[1]
-        v = res[0]
+        v = json.loads(json.dumps(res[0]))               # the line bench.py prints must serialise
         assert v["checked"] and v["utterances"] == 64 and v["graded_over_ranks"] == 2
         if spoil:
             assert not v["ok"] and v["utterances_identical_over_all_frames"] == 63
         else:
             assert v["ok"] and v["utterances_identical_over_all_frames"] == 64
             assert v["identical_leading_frames"] == {"min": 64, "total": 4096, "of": 4096}
+
+
+def test_result_check_at_one_rank_serialises():
+    """The single-GPU form of the check, on the fixture's own ids: 32 utterances identical, and the dict is plain JSON."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import bench
+    g = np.load(os.path.join(ROOT, "tests", "golden", "bench_b32_f64.npz"))
+    codes = np.ascontiguousarray(g["ids"].astype(np.int32).transpose(1, 0, 2))      # [frames][slots][16]
+    prefixes, n_text, pad = bench.workload(32, 0, 1234, 1)
+    v = json.loads(json.dumps(bench.verify_against_fixture(codes, 32, 64, 1234, 1, prefixes, n_text, pad)))
+    assert v["checked"] is True and v["ok"] is True and v["utterances"] == 32
+    assert v["identical_leading_frames"] == {"min": 64, "total": 2048, "of": 2048, "median": 64}
+    # other inputs than the fixture's: reported as unchecked, never as a pass
+    v = bench.verify_against_fixture(codes, 32, 64, 1235, 1, *bench.workload(32, 0, 1235, 1))
+    assert v["checked"] is False and "ok" not in v
