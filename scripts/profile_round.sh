@@ -7,7 +7,8 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-fail() { echo "$1 failed"; exit 1; }
+# (a failed step must not leave the trace database behind: gpurun copies gpurun_out/ back only below 64 MiB)
+fail() { echo "$1 failed"; find $O -name "*.db" -size +20M -delete; find $O -name "*_kernel_trace.csv" -size +20M -delete; exit 1; }
 # 1. per-kernel time of the benchmark command, eager launches (rocprofv3's kernel trace cannot follow the graph replay);
 #    the profiler run keeps the runtime's four hardware queues (it hangs with one)
 GPU_MAX_HW_QUEUES=4 Q3_NO_GRAPH=1 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python3 $R/bench.py --steps 3 --warmup 1 --no-timeline --no-cpu --no-longform --no-ragged > $O/bench_prof.log 2> $O/bench_prof.err || { tail -3 $O/bench_prof.err; fail "kernel trace"; }
