@@ -11,8 +11,8 @@ One "step" = one pass of the hot path over one batch of synthetic utterances: ra
 prompts + F autoregressive frames (talker step, 15-group code predictor, feedback) for all of them
 + the fp32 vocoder chunk (F=64 frames -> 5.12 s of 24 kHz audio) of every utterance; the vocoder of
 step i is submitted from a second thread on its own stream while the frame loop of step i+1 proceeds (the
-streaming arrangement of the reference client, tts_client.py:188-197; on the chip the two do not overlap --
-profiles/r02_coscheduling.md -- so a step costs their sum).  Weights and prefix embeddings are resident before the
+streaming arrangement of the reference client, tts_client.py:188-197; the decode then runs on one persistent
+workgroup per CU, voc_set_max_workgroups(-1), which is what lets the two share the chip: DESIGN.md section 4).  Weights and prefix embeddings are resident before the
 timed region.  Utterances are independent:
 the N*B utterances of a job (config 4: 256 = the 32 prompts x 8) are sorted by expected length (3 frames per
 text token, the reference's own estimate: llamacpp_talker_server.py:174) and dealt round-robin to the N ranks; no
@@ -57,7 +57,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (config 3/4: 32)")
     ap.add_argument("--frames", type=int, default=64, help="frames per utterance per step (one vocoder chunk)")
     ap.add_argument("--chains", type=int, default=0, help="parallel row groups per frame (0 = engine default)")
-    ap.add_argument("--voc-wgs", type=int, default=-1, help="cap of workgroups per vocoder launch (-1 = default)")
+    ap.add_argument("--voc-wgs", type=int, default=-1,
+                    help="workgroups per vocoder launch while it runs beside the frame loop: -1 = one per compute unit (default, the "
+                         "measured optimum), 0 = one per tile (no cap), N = N")
     ap.add_argument("--no-vocoder", action="store_true", help="time the talker + code-predictor loop only")
     ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 latency leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -658,8 +660,9 @@ def main():
     if not a.no_vocoder:
         if F != 64:
             raise SystemExit("bench.py: the vocoder leg decodes 64-frame chunks; use --frames 64 or --no-vocoder")
-        if a.voc_wgs >= 0:
-            lib.voc_set_max_workgroups(a.voc_wgs)
+        # the decode of step s runs beside the frame loop of step s + 1: one persistent vocoder workgroup per CU leaves the frame
+        # loop's workgroups room (include/qwen3tts_voc.h; 244 -> 232 ms per step).  Same tiles, same bits.
+        voc_cap = lib.voc_set_max_workgroups(a.voc_wgs)
         voc = Vocoder(lib, make_voc_pack(a.cache, a.seed, rank, barrier), B)
         # headline arithmetic = exact fp32 (north_star: "fused fp32 HIP kernel"); the 2 x fp16 split-operand mode
         # (fp32-grade against float64) is reported beside it as an option
@@ -667,15 +670,20 @@ def main():
     dt, frame_ms_step, prefill_ms, voc_ms = run_leg(eng, voc, prefixes, n_text, pad, F, a.steps, a.warmup, sync_all)
     verified = verify_against_fixture(run_leg.last_codes, B, F, a.seed, world, prefixes, n_text, pad, rank, R)
     # the frame graph alone on the chip (inside a step the previous step's vocoder chunk runs beside it and the two
-    # split the machine: the step time is their sum either way, the kernel-quality figure is this one)
+    # share the machine; the kernel-quality figure is this one)
     eng.start(prefixes, n_text, ignore_eos=True, max_frames=F)
     assert eng.run(F) == F
     frame_ms = eng.last_run_ms / F
     voc_ms_step = voc_ms
-    if voc is not None:      # likewise one 32-chunk decode alone
+    voc_ms_cap_alone = None
+    if voc is not None:      # likewise one 32-chunk decode alone: with the co-run grid, then with one workgroup per tile (the kernels' own rate)
         codes_alone, _ = eng.codes()
         voc.decode(codes_alone.copy())
+        voc_ms_cap_alone = float(voc.ms[-1])
+        lib.voc_set_max_workgroups(0)
+        voc.decode(codes_alone.copy())
         voc_ms = float(voc.ms[-1])
+        lib.voc_set_max_workgroups(voc_cap)
     step_w_bytes = eng.step_weight_bytes
     dt = R.max_over_ranks(dt)
     value = aggregate_value(world, B, F, a.steps, dt)
@@ -711,13 +719,18 @@ def main():
                                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": round(fl / (voc_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                                    "traffic": None, "flops_per_launch": fl, "avg_launch_ms": round(voc_ms, 3),
+                                   "grid": "one workgroup per tile (the decode has the GPU to itself)",
+                                   "co_run_grid_workgroups": int(voc_cap),
+                                   "avg_launch_ms_co_run_grid_alone": round(voc_ms_cap_alone, 3),
                                    "avg_launch_ms_beside_frame_loop": round(voc_ms_step, 3)}
         # the optional arithmetic: every f32 operand as two fp16 terms, 3 fp16 MFMAs per product, f32 accumulate
         # (executed MFMA flops = 3 x table flops): one decode alone, and two whole steps (rank 0, N = 1)
         if world == 1:
             lib.voc_set_exact_fp32(0)
+            lib.voc_set_max_workgroups(0)
             voc.decode(codes_alone.copy())
             sp_ms = float(voc.ms[-1])
+            # (no cap here: this decode is short enough that giving the frame loop room costs more than it returns, 8.8 k vs 9.5 k)
             dt_sp, _, _, _ = run_leg(eng, voc, prefixes, n_text, pad, F, 2, 1, sync_all)
             lib.voc_set_exact_fp32(1)
             vt = Vocoder(lib, make_voc_pack(a.cache, a.seed, rank, barrier, trunk_only=True), B)
@@ -734,6 +747,9 @@ def main():
                                           "ms_per_step_with_split_vocoder": round(dt_sp / 2 * 1e3, 3)}
         voc.close()
     eng.destroy()
+    # the other legs run without a cap (measured with one workgroup per CU: one utterance 449.6 vs 447.4 frames/s, its chunk 11.8
+    # instead of 9.1 ms; natural lengths 6.60 k vs 6.73 k; the long-form walk runs after its loop)
+    lib.voc_set_max_workgroups(0)
     if world == 1 and not a.no_b1:
         eng1 = FrameEngine(path, max_batch=1, n_ctx=n_ctx, max_frames=F)
         voc1 = Vocoder(lib, make_voc_pack(a.cache, a.seed, rank, barrier), 1) if not a.no_vocoder else None

@@ -25,6 +25,7 @@ extern "C" {
  * CPU path), and selection of the device used by handles created afterwards (one process per GPU:
  * the per-GPU launcher sets HIP_VISIBLE_DEVICES, a torchrun rank passes LOCAL_RANK). */
 int q3_device_count(void);
+int q3_device_compute_units(void);   /* compute units of the current device (256 on an MI355X) */
 int q3_set_device(int device);
 
 /* weights: Q3TTSW1 container with talker.* and cp.*.  max_batch utterances at once, n_ctx talker

@@ -85,9 +85,13 @@ int voc_set_exact_fp32(int on);
  * per conv (the 1x1 conv then sums its channels in a different order: results differ in the last f32 bit). */
 int voc_set_fused_units(int on);
 
-/* Cap the workgroups each vocoder kernel launch occupies (0 = one per output tile).  With a cap the
- * kernels walk their tiles persistently and leave the other compute units to a concurrently running
- * frame loop (talker / code predictor), which is latency-bound and would otherwise starve. */
+/* Cap the workgroups each vocoder kernel launch occupies (0 = one per output tile, the default and the fastest for a decode that
+ * has the GPU to itself; -1 = one per compute unit of the current device).  With a cap the kernels walk their tiles persistently
+ * -- same tiles, same sums, same bits -- and leave registers and LDS of every compute unit to a concurrently running frame loop
+ * (talker / code predictor), which is latency-bound and otherwise finds room only in the tails of the vocoder's launches.  Measured
+ * on MI355X, 32 utterances, frame loop of step s + 1 beside the decode of step s: exactly one workgroup per CU is the optimum
+ * (the decode alone 89 -> 125 ms, the frame step beside it 2.40 -> 3.2 ms instead of starving, the whole step 244 -> 232 ms);
+ * 192 / 224 / 288 / 320 / 512 workgroups: 255 / 243 / 281 / 272 / 241 ms.  Returns the cap in effect.  Process-wide. */
 int voc_set_max_workgroups(int n);
 
 /* GPU milliseconds of the last voc_decode (HIP events on the library's stream) and its FLOP count. */

@@ -13,6 +13,11 @@ utterance.  Extension of the wire protocol, same conventions (little-endian, u32
               i32 n_frames, i32[n_frames*16] codes, i32 n_samples, i16[n_samples] PCM (24 kHz)
 
 One process per GPU (HIP_VISIBLE_DEVICES), like the other servers.
+
+`--pipeline`: the vocoder of request k runs on a worker thread (and replies on k's connection) while the frame loop of request
+k + 1 already runs -- the reference's client does the same per 64-frame block of ONE utterance (tts_client.py:188-197).  The
+vocoder then launches one persistent workgroup per compute unit (voc_set_max_workgroups(-1)), which leaves the frame loop's
+workgroups room beside it (244 -> 232 ms per 32 x 64-frame step); results are bit-identical.
 """
 from __future__ import annotations
 
@@ -35,7 +40,7 @@ from .weights import ModelConfig, read_pack
 class BatchSynthesisServer:
     def __init__(self, model_path, vocoder_path, socket_path="/tmp/qwen3_batch.sock", max_batch=32, n_ctx=512,
                  max_tokens=200, temperature=0.0, top_k=50, cp_temperature=0.0, tokenizer=None, seed=0,
-                 install_signal_handlers=True, max_request=None):
+                 install_signal_handlers=True, max_request=None, pipeline=False):
         self.socket_path, self.max_batch, self.max_tokens = socket_path, max_batch, max_tokens
         # utterances one request may queue (the server is single-threaded: an unbounded request holds it indefinitely)
         self.max_request = int(max_request) if max_request else 8 * max_batch
@@ -56,6 +61,12 @@ class BatchSynthesisServer:
         self.voc = self._lib.voc_load(str(vocoder_path).encode(), 64, min(max_batch, 32))
         if not self.voc:
             raise RuntimeError(f"voc_load failed: {vocoder_path}")
+        self.pipeline = bool(pipeline)
+        self._pool = None
+        if self.pipeline:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=1)       # ONE worker: the vocoder handle has one caller, replies keep their order
+            self._lib.voc_set_max_workgroups(-1)
         self._running = True
         if install_signal_handlers:
             signal.signal(signal.SIGINT, self._signal_handler)
@@ -71,8 +82,8 @@ class BatchSynthesisServer:
             raise RuntimeError("no tokenizer configured (--tokenizer DIR) and the request has no token_ids")
         return [self.tokenizer.encode(t, add_special_tokens=False) for t in msg.get("texts", [])]
 
-    def synthesize(self, token_ids, max_tokens=None):
-        """-> list of (codes int32 [n_frames][16], pcm int16) per utterance."""
+    def generate(self, token_ids, max_tokens=None):
+        """The frame loop of a request -> list of codes int32 [n_frames][16] per utterance."""
         B = len(token_ids)
         if B == 0:
             raise ValueError("a request needs at least one utterance")
@@ -96,9 +107,13 @@ class BatchSynthesisServer:
             self.eng.run(max_tokens)
             codes, per = self.eng.codes()
             per_utt = [codes[:int(per[b]), b, :] for b in range(B)]
-        # the vocoder: every utterance's chunk walk in ONE batched call (voc_synthesize_batch: chunks of all utterances
-        # decoded together, overlap-crossfade assembled on the device; per utterance = VocoderServer.synthesize + int16)
-        cs = [np.ascontiguousarray(per_utt[b], dtype=np.int32) for b in range(B)]
+        return [np.ascontiguousarray(c, dtype=np.int32) for c in per_utt]
+
+    def vocode(self, cs):
+        """The vocoder of a request: every utterance's chunk walk in ONE batched call (voc_synthesize_batch: chunks of all
+        utterances decoded together, overlap-crossfade assembled on the device; per utterance = VocoderServer.synthesize +
+        int16) -> list of (codes, pcm int16)."""
+        B = len(cs)
         live = [b for b in range(B) if cs[b].shape[0] > 0]
         pcm = {b: np.zeros(0, np.int16) for b in range(B)}
         if live:
@@ -112,8 +127,26 @@ class BatchSynthesisServer:
                 raise RuntimeError("voc_synthesize_batch failed")
             for k, b in enumerate(live):
                 pcm[b] = buf[off[k]:off[k + 1]].copy()
-        out = [(cs[b], pcm[b]) for b in range(B)]
-        return out
+        return [(cs[b], pcm[b]) for b in range(B)]
+
+    def synthesize(self, token_ids, max_tokens=None):
+        """-> list of (codes int32 [n_frames][16], pcm int16) per utterance."""
+        return self.vocode(self.generate(token_ids, max_tokens))
+
+    def _finish(self, conn, cs, t0):
+        """Worker side of the pipelined mode: vocode, reply on the request's own connection, close it."""
+        try:
+            res = self.vocode(cs)
+            conn.sendall(pack_batch_reply(res))
+            print(f"  {len(res)} utterances, {sum(len(c) for c, _ in res)} frames in {time.time() - t0:.3f}s")
+        except Exception as e:
+            print(f"Error: {e}")
+            try:
+                conn.sendall(P.pack_sentinel(P.SENTINEL_ERROR))
+            except OSError:
+                pass
+        finally:
+            conn.close()
 
     def serve(self):
         if os.path.exists(self.socket_path):
@@ -131,11 +164,18 @@ class BatchSynthesisServer:
                 continue
             except OSError:
                 break
+            handed_over = False
             try:
                 msg = P.read_talker_request(conn)
                 if msg is None:
                     continue
                 t0 = time.time()
+                if self._pool is not None:
+                    # pipelined: this request's vocoder runs on the worker while the loop accepts and generates the next one
+                    cs = self.generate(self._token_ids(msg), msg.get("max_tokens"))
+                    self._pool.submit(self._finish, conn, cs, t0)
+                    handed_over = True
+                    continue
                 res = self.synthesize(self._token_ids(msg), msg.get("max_tokens"))
                 conn.sendall(pack_batch_reply(res))
                 frames = sum(len(c) for c, _ in res)
@@ -147,13 +187,22 @@ class BatchSynthesisServer:
                 except OSError:
                     pass
             finally:
-                conn.close()
+                if not handed_over:
+                    conn.close()
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)       # replies in flight go out before the socket disappears
+            self._pool = None
         sock.close()
         if os.path.exists(self.socket_path):
             os.unlink(self.socket_path)
 
     def close(self):
         self._running = False
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+        if self.pipeline:
+            self._lib.voc_set_max_workgroups(0)
         if self.voc:
             self._lib.voc_free(self.voc)
             self.voc = None
@@ -224,9 +273,11 @@ def main():
     ap.add_argument("--top_k", type=int, default=50)
     ap.add_argument("--cp_temperature", type=float, default=0.1)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--pipeline", action="store_true",
+                    help="vocode request k on a worker thread while request k + 1 generates (one vocoder workgroup per CU)")
     a = ap.parse_args()
     srv = BatchSynthesisServer(a.model, a.vocoder, a.socket, a.max_batch, a.n_ctx, a.max_tokens, a.temperature, a.top_k,
-                               a.cp_temperature, a.tokenizer, a.seed)
+                               a.cp_temperature, a.tokenizer, a.seed, pipeline=a.pipeline)
     try:
         srv.serve()
     finally:

@@ -209,5 +209,12 @@ extern "C" int q3_device_count(void) {
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
+// Compute units of the current device (256 on an MI355X); 0 when there is none.
+extern "C" int q3_device_compute_units(void) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+    return p.multiProcessorCount;
+}
 // Select the HIP device used by every handle created afterwards on this thread.
 extern "C" int q3_set_device(int dev) { return hipSetDevice(dev) == hipSuccess ? 0 : -1; }

@@ -1720,9 +1720,14 @@ int voc_set_fused_units(int on) {   // 1 (default): residual units at 96 / 192 c
     return 0;
 }
 
-int voc_set_max_workgroups(int n) {
-    g_voc_max_wgs = n < 0 ? 0 : n;
-    return 0;
+int voc_set_max_workgroups(int n) {   // -> the cap in effect (0 = none)
+    if (n < 0) {   // one persistent workgroup per compute unit: the co-run setting (qwen3tts_voc.h)
+        int dev = 0;
+        hipDeviceProp_t p;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 0;
+    }
+    g_voc_max_wgs = n;
+    return n;
 }
 
 int voc_chunk_tokens(void* vv) { return vv ? ((Voc*)vv)->chunk : 0; }

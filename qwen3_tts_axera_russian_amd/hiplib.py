@@ -108,6 +108,7 @@ def load(path: str | None = None):
     _sig(lib, "tfe_build_prefix", c_int, [c_void_p, i32p, c_int, i32p, f32p])
     _sig(lib, "tfe_tts_pad_embed", c_int, [c_void_p, f32p])
     _sig(lib, "q3_device_count", c_int, [])
+    _sig(lib, "q3_device_compute_units", c_int, [])
     _sig(lib, "q3_set_device", c_int, [c_int])
     if path is None:
         _lib = lib

@@ -153,6 +153,57 @@ def test_batch_server_matches_single_utterance_path(gpu_lib, packs, tmp_path):
     srv.close()
 
 
+def test_pipelined_batch_server_replies_are_the_unpipelined_ones(gpu_lib, packs, tmp_path):
+    """--pipeline: request k is vocoded on a worker thread (one persistent vocoder workgroup per CU) while request k + 1 already
+    generates.  Three clients connect at once; every one gets, on its own connection, exactly what the synchronous server
+    computes for its request (ids and PCM bit for bit); a bad request in between gets the error sentinel."""
+    import socket
+    import struct
+    from qwen3_tts_axera_russian_amd import batch_server as bs
+    main, voc, cfg = packs
+    reqs = [[[5, 17, 200, 33, 41, 7, 90, 120, 64, 3, 11, 250, 77, 8, 19, 300, 45, 60, 2, 150, 99, 21, 13, 55, 180], [9, 8, 7]],
+            [[301, 302, 303, 304, 305, 306, 307, 308, 309, 310, 311, 312], [], [4, 4, 4, 4]],
+            [[9, 8, 7, 6, 5]]]
+    want = []
+    ref = bs.BatchSynthesisServer(main, voc, str(tmp_path / "ref.sock"), max_batch=4, n_ctx=128, max_tokens=70, temperature=0.0,
+                                  cp_temperature=0.0, install_signal_handlers=False)
+    for r in reqs:
+        want.append(ref.synthesize(r))
+    ref.close()
+    sock = str(tmp_path / "pipe.sock")
+    srv = bs.BatchSynthesisServer(main, voc, sock, max_batch=4, n_ctx=128, max_tokens=70, temperature=0.0, cp_temperature=0.0,
+                                  install_signal_handlers=False, pipeline=True)
+    assert gpu_lib.voc_set_max_workgroups(-1) == gpu_lib.q3_device_compute_units()      # the setting the server made
+    th = threading.Thread(target=srv.serve, daemon=True)
+    th.start()
+    _wait(sock)
+    got = [None] * len(reqs)
+
+    def client(i):
+        got[i] = bs.synthesize_batch(sock, token_ids=reqs[i])
+    ts = [threading.Thread(target=client, args=(i,)) for i in range(len(reqs))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    for i, r in enumerate(reqs):
+        assert got[i] is not None and len(got[i]) == len(r)
+        for (codes, pcm), (wc, wp) in zip(got[i], want[i]):
+            np.testing.assert_array_equal(codes, wc)
+            np.testing.assert_array_equal(pcm, wp)
+    s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    s.connect(sock)
+    s.sendall(bs.pack_batch_request(token_ids=[]))
+    assert struct.unpack("<i", s.recv(4))[0] == -2
+    s.close()
+    again = bs.synthesize_batch(sock, token_ids=reqs[2])
+    np.testing.assert_array_equal(again[0][1], want[2][0][1])
+    srv._running = False
+    th.join(timeout=10)
+    srv.close()
+    assert gpu_lib.voc_set_max_workgroups(0) == 0
+
+
 def test_native_cp_server_binary(gpu_lib, packs, tmp_path):
     """The native code-predictor server (csrc/cp_server_main.cpp, the reference's code_predictor_cpp /
     code_predictor_ggml binaries): 4100 bytes in, 60 bytes out, one connection per frame; greedy codes equal

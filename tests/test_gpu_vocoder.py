@@ -192,6 +192,7 @@ def test_full_size_table_is_causal_and_deterministic(gpu_lib, tmp_path_factory):
     vocoder_server.py:84-117);
     a chunk decodes to the same samples alone and inside a batch; and twice the same input gives the same bits."""
     path = os.path.join(CACHE, "voc_whole_s1234.q3w")
+    os.makedirs(CACHE, exist_ok=True)
     if not os.path.exists(path):
         W.write_pack(path, {"voc_chunk": 64.0}, W.make_synthetic_voc(W.VocConfig(), seed=1234))
     v = Voc(gpu_lib, path, max_batch=3)
@@ -216,6 +217,28 @@ def test_full_size_table_is_causal_and_deterministic(gpu_lib, tmp_path_factory):
     v.close()
 
 
+def test_capped_grid_decodes_to_the_same_bits(gpu_lib):
+    """voc_set_max_workgroups(n): every kernel walks its tiles persistently with at most n workgroups (-1: one per compute unit,
+    the setting that leaves room for the frame loop's workgroups when the two run side by side).  The tile a column belongs to
+    and the order of its sums do not change: same bits as the one-workgroup-per-tile launch, at the full-size table, for a cap
+    below and a cap above the smaller ops' tile counts and for the per-CU setting."""
+    path = os.path.join(CACHE, "voc_whole_s1234.q3w")
+    os.makedirs(CACHE, exist_ok=True)
+    if not os.path.exists(path):
+        W.write_pack(path, {"voc_chunk": 64.0}, W.make_synthetic_voc(W.VocConfig(), seed=1234))
+    v = Voc(gpu_lib, path, max_batch=3)
+    codes = np.random.default_rng(23).integers(0, 2048, size=(3, 64, 16)).astype(np.int64)
+    gpu_lib.voc_set_max_workgroups(0)
+    want = v.decode(codes).copy()
+    try:
+        for cap in (64, 256, -1):
+            assert gpu_lib.voc_set_max_workgroups(cap) == (cap if cap > 0 else gpu_lib.q3_device_compute_units())
+            np.testing.assert_array_equal(v.decode(codes), want)
+    finally:
+        gpu_lib.voc_set_max_workgroups(0)
+    v.close()
+
+
 def test_short_chunks_decode_at_their_own_length_to_the_same_bits(gpu_lib):
     """The chunk walk decodes a chunk of n < 64 frames at n + 1 frames rounded up to 8 (voc_decode_frames) instead of the
     reference's zero-padded 64 (vocoder_server.py:78-81): the decoder is causal but for a quarter frame of look-ahead,
@@ -223,6 +246,7 @@ def test_short_chunks_decode_at_their_own_length_to_the_same_bits(gpu_lib):
     table, where the shorter activations would otherwise pick other kernel variants (other summation orders), for the
     single-utterance entry point and for the batched one (chunks of one decode length share a launch)."""
     path = os.path.join(CACHE, "voc_whole_s1234.q3w")
+    os.makedirs(CACHE, exist_ok=True)
     if not os.path.exists(path):
         W.write_pack(path, {"voc_chunk": 64.0}, W.make_synthetic_voc(W.VocConfig(), seed=1234))
     v = Voc(gpu_lib, path, max_batch=4)
@@ -253,6 +277,7 @@ def test_full_size_table_matches_torch_reference_in_both_arithmetic_modes(gpu_li
     2 x fp16 split-operand mode, tolerance 2e-4 of full scale (the waveform is clamped to [-1, 1]); plus the
     second chunk of a batch of two, so the batch index of the tiling is covered."""
     path = os.path.join(CACHE, "voc_whole_s1234.q3w")
+    os.makedirs(CACHE, exist_ok=True)
     if not os.path.exists(path):
         W.write_pack(path, {"voc_chunk": 64.0}, W.make_synthetic_voc(W.VocConfig(), seed=1234))
     _, tensors = W.read_pack(path)
@@ -279,6 +304,7 @@ def test_fused_residual_units_equal_the_per_conv_launches(gpu_lib):
     the order in which the 1x1 conv sums its channels: outputs of the whole default table agree to 2e-6 of full
     scale with the three-launch form, at a ragged batch (3 chunks) so the column tail of the tiling is covered."""
     path = os.path.join(CACHE, "voc_whole_s1234.q3w")
+    os.makedirs(CACHE, exist_ok=True)
     if not os.path.exists(path):
         W.write_pack(path, {"voc_chunk": 64.0}, W.make_synthetic_voc(W.VocConfig(), seed=1234))
     codes = np.random.default_rng(33).integers(0, 2048, size=(3, 64, 16)).astype(np.int64)
