@@ -169,6 +169,7 @@ class Vocoder:
         self.h = lib.voc_load(path.encode(), chunk, max_batch)
         if not self.h:
             raise SystemExit("bench.py: voc_load failed")
+        self.cap = 0      # workgroups per launch while a frame loop runs beside the decode (run_leg re-arms it; 0 = one per tile)
         self.chunk, self.spt = lib.voc_chunk_tokens(self.h), lib.voc_samples_per_token(self.h)
         self.out = np.empty((max_batch, lib.voc_chunk_samples(self.h)), np.float32)   # the model's output rows (<= chunk * spt)
         self.ms = []
@@ -192,16 +193,22 @@ def run_leg(eng, voc, prefixes, n_text, pad, frames, steps, warmup, sync_all):
     eng.set_pad_embed(pad)
     pool = ThreadPoolExecutor(max_workers=1)
 
-    def one_step(pending):
+    def one_step(pending, last=False):
         eng.start(prefixes, n_text, ignore_eos=True, max_frames=frames)
         ran = eng.run(frames)
         assert ran == frames
         codes, _ = eng.codes()
         if pending is not None:
             pending.result()
-        return pool.submit(voc.decode, codes.copy()) if voc is not None else None
+        if voc is None:
+            return None
+        if last:      # the queue drains: no frame loop runs beside the last decode, it takes the whole chip (one workgroup per tile)
+            voc.lib.voc_set_max_workgroups(0)
+        return pool.submit(voc.decode, codes.copy())
 
     pending = None
+    if voc is not None:
+        voc.lib.voc_set_max_workgroups(voc.cap)      # the grid of a decode that runs beside a frame loop (0 = one workgroup per tile)
     for _ in range(warmup):
         pending = one_step(pending)
     if pending is not None:
@@ -212,8 +219,8 @@ def run_leg(eng, voc, prefixes, n_text, pad, frames, steps, warmup, sync_all):
     sync_all()
     t0 = time.perf_counter()
     pending = None
-    for _ in range(steps):
-        pending = one_step(pending)
+    for i in range(steps):
+        pending = one_step(pending, last=(i == steps - 1))
         frame_ms.append(eng.last_run_ms / frames)
         prefill_ms.append(eng.last_prefill_ms)
     if pending is not None:
@@ -664,6 +671,7 @@ def main():
         # loop's workgroups room (include/qwen3tts_voc.h; 244 -> 232 ms per step).  Same tiles, same bits.
         voc_cap = lib.voc_set_max_workgroups(a.voc_wgs)
         voc = Vocoder(lib, make_voc_pack(a.cache, a.seed, rank, barrier), B)
+        voc.cap = voc_cap
         # headline arithmetic = exact fp32 (north_star: "fused fp32 HIP kernel"); the 2 x fp16 split-operand mode
         # (fp32-grade against float64) is reported beside it as an option
         lib.voc_set_exact_fp32(1)
@@ -678,12 +686,12 @@ def main():
     voc_ms_cap_alone = None
     if voc is not None:      # likewise one 32-chunk decode alone: with the co-run grid, then with one workgroup per tile (the kernels' own rate)
         codes_alone, _ = eng.codes()
+        lib.voc_set_max_workgroups(voc_cap)
         voc.decode(codes_alone.copy())
         voc_ms_cap_alone = float(voc.ms[-1])
         lib.voc_set_max_workgroups(0)
         voc.decode(codes_alone.copy())
         voc_ms = float(voc.ms[-1])
-        lib.voc_set_max_workgroups(voc_cap)
     step_w_bytes = eng.step_weight_bytes
     dt = R.max_over_ranks(dt)
     value = aggregate_value(world, B, F, a.steps, dt)
@@ -730,7 +738,7 @@ def main():
             lib.voc_set_max_workgroups(0)
             voc.decode(codes_alone.copy())
             sp_ms = float(voc.ms[-1])
-            # (no cap here: this decode is short enough that giving the frame loop room costs more than it returns, 8.8 k vs 9.5 k)
+            # (the co-run grid here too: 9.93 k against 9.48 k frames/s with one workgroup per tile)
             dt_sp, _, _, _ = run_leg(eng, voc, prefixes, n_text, pad, F, 2, 1, sync_all)
             lib.voc_set_exact_fp32(1)
             vt = Vocoder(lib, make_voc_pack(a.cache, a.seed, rank, barrier, trunk_only=True), B)

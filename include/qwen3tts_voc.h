@@ -90,8 +90,9 @@ int voc_set_fused_units(int on);
  * -- same tiles, same sums, same bits -- and leave registers and LDS of every compute unit to a concurrently running frame loop
  * (talker / code predictor), which is latency-bound and otherwise finds room only in the tails of the vocoder's launches.  Measured
  * on MI355X, 32 utterances, frame loop of step s + 1 beside the decode of step s: exactly one workgroup per CU is the optimum
- * (the decode alone 89 -> 125 ms, the frame step beside it 2.40 -> 3.2 ms instead of starving, the whole step 244 -> 232 ms);
- * 192 / 224 / 288 / 320 / 512 workgroups: 255 / 243 / 281 / 272 / 241 ms.  Returns the cap in effect.  Process-wide. */
+ * (the decode alone 89 -> 125 ms, the frame step beside it 2.40 -> 2.9 ms instead of starving, the whole step 244 -> 209 ms with the
+ * frame loop's waves at raised priority, which the library's kernels set themselves); 320 / 384 / 512 / 768 workgroups: 239 / 228 /
+ * 234 / 245 ms.  Returns the cap in effect.  Process-wide. */
 int voc_set_max_workgroups(int n);
 
 /* GPU milliseconds of the last voc_decode (HIP events on the library's stream) and its FLOP count. */

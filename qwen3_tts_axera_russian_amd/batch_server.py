@@ -17,7 +17,7 @@ One process per GPU (HIP_VISIBLE_DEVICES), like the other servers.
 `--pipeline`: the vocoder of request k runs on a worker thread (and replies on k's connection) while the frame loop of request
 k + 1 already runs -- the reference's client does the same per 64-frame block of ONE utterance (tts_client.py:188-197).  The
 vocoder then launches one persistent workgroup per compute unit (voc_set_max_workgroups(-1)), which leaves the frame loop's
-workgroups room beside it (244 -> 232 ms per 32 x 64-frame step); results are bit-identical.
+workgroups room beside it (244 -> 209 ms per 32 x 64-frame step); results are bit-identical.
 """
 from __future__ import annotations
 

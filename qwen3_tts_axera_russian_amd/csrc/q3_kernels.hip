@@ -67,7 +67,19 @@ struct TlScope2 {
         if (tl_scope_.slot < g_tl_cap && g_ph) g_ph[(size_t)tl_scope_.slot * 8 + (n)] = wall_clock64(); \
     } while (0)
 #else
+// Every kernel of the frame loop (and the prefill) raises its waves' issue priority at entry (s_setprio 3; -DQ3_WAVE_PRIO=0 builds
+// without).  Alone on the chip it changes nothing (2.40 ms per frame step either way).  Beside the vocoder's one-workgroup-per-CU
+// grid (voc_set_max_workgroups(-1)) a frame-loop wave shares its SIMD with one vocoder wave that issues MFMAs and LDS reads back to
+// back; with priority the frame step beside the decode takes 3.0 instead of 3.2 ms and the benchmark's step 211 instead of 232 ms
+// (round 2 tried the priority beside an UNCAPPED vocoder grid, where the frame loop's workgroups found no room at all: no effect).
+#ifndef Q3_WAVE_PRIO
+#define Q3_WAVE_PRIO 3
+#endif
+#if Q3_WAVE_PRIO > 0
+#define Q3_TL(id) __builtin_amdgcn_s_setprio(Q3_WAVE_PRIO)
+#else
 #define Q3_TL(id)
+#endif
 #define Q3_PH(n)
 #endif
 
