@@ -397,6 +397,7 @@ def ragged_leg(lib, path, voc_path, B, seed, rounds=3, max_frames=256):
     eng = FrameEngine(path, max_batch=B, n_ctx=max(p.shape[0] for p in prefixes) + max_frames + 8, max_frames=max_frames)
     eng.set_pad_embed(pad)
     lib.voc_set_exact_fp32(1)
+    lib.voc_set_max_workgroups(0)     # (the per-CU grid loses here: 6.20 k against 6.91 k frames/s -- small ragged launches, long tails)
     h = lib.voc_load(voc_path.encode(), 64, B)
     if not h:
         raise SystemExit("bench.py: voc_load failed (ragged leg)")
@@ -755,8 +756,8 @@ def main():
                                           "ms_per_step_with_split_vocoder": round(dt_sp / 2 * 1e3, 3)}
         voc.close()
     eng.destroy()
-    # the other legs run without a cap (measured with one workgroup per CU: one utterance 449.6 vs 447.4 frames/s, its chunk 11.8
-    # instead of 9.1 ms; natural lengths 6.60 k vs 6.73 k; the long-form walk runs after its loop)
+    # the other legs run without a cap (measured with one workgroup per CU: one utterance 452.8 vs 448.0 frames/s, its chunk 11.2
+    # instead of 9.3 ms; natural lengths 6.20 k vs 6.91 k; the long-form walk runs after its loop)
     lib.voc_set_max_workgroups(0)
     if world == 1 and not a.no_b1:
         eng1 = FrameEngine(path, max_batch=1, n_ctx=n_ctx, max_frames=F)
