@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--csv", default=None)
     ap.add_argument("--json", action="store_true")
+    ap.add_argument("--beside-vocoder", type=int, default=None, metavar="WGS",
+                    help="record the frame while 32-chunk vocoder decodes run on a second thread with voc_set_max_workgroups(WGS) "
+                         "(-1 = one workgroup per CU, 0 = one per tile): where the frame step's time goes beside the decode")
     ap.add_argument("--cache", default=os.environ.get("Q3_BENCH_CACHE", "/tmp/q3_bench_cache"))
     a = ap.parse_args()
     if not os.path.exists(TL):
@@ -80,8 +83,28 @@ def main():
     lib.q3t_tl2_begin(cap)
     # numbering is assigned at launch / capture time: this run re-captures nothing, so number the nodes by one eager
     # frame + capture of a fresh engine state instead: destroy the graph by switching the frame budget
+    stop, th, voc = [False], None, None
+    if a.beside_vocoder is not None:
+        import threading
+        import time
+        lib.voc_set_exact_fp32(1)
+        lib.voc_set_max_workgroups(a.beside_vocoder)
+        voc = bench.Vocoder(lib, bench.make_voc_pack(a.cache, 1234, 0, lambda: None), 32)
+        codes = np.random.default_rng(0).integers(0, 2048, size=(64, 32, 16)).astype(np.int32)
+
+        def churn():
+            while not stop[0]:
+                voc.decode(codes)
+        th = threading.Thread(target=churn, daemon=True)
+        th.start()
+        time.sleep(1.0)             # the first decode (LDS attributes, clocks) is over, one is running now
     eng.start(prefixes, n_text, ignore_eos=True, max_frames=63)
     eng.run(12)                     # frame 0 eager (nodes 0..n-1), capture (nodes n..2n-1), 10 replays
+    if th is not None:
+        stop[0] = True
+        th.join()
+        voc.close()
+        lib.voc_set_max_workgroups(0)
     buf = (ctypes.c_ulonglong * (cap * MAXB * 2))()
     n = lib.q3t_tl2_end(buf, cap)
     kinds = (ctypes.c_int * cap)()
