@@ -1293,6 +1293,7 @@ static inline long convt_cols(const VocOp& op, long L) {
 }
 
 struct Voc {
+    int device = 0;           // the HIP device the handle was loaded on (q3_set_device before voc_load); entry points bind their thread to it
     int chunk = 64, max_batch = 1, upsample = 1;
     long chunk_samples = 0;   // what one decode of `chunk` frames yields (<= chunk * upsample: the transposed convs trim)
     std::vector<VocOp> ops;
@@ -1366,9 +1367,20 @@ static void voc_destroy(Voc* v) {
 
 using namespace q3;
 
+// A handle's buffers, stream and events live on the device it was loaded on.  The HIP current device is a per-THREAD setting that
+// starts at 0: a worker thread of a process that drives GPU k (one rank of a multi-GPU job, all GPUs visible) would otherwise launch
+// the decode's kernels with the wrong device current.  Every entry point that touches the GPU binds its thread first.
+static inline void voc_bind(const Voc* v) {
+    int d = -1;
+    if (v && (hipGetDevice(&d) != hipSuccess || d != v->device)) hipSetDevice(v->device);
+}
+
 extern "C" {
 
-void voc_free(void* vv) { voc_destroy((Voc*)vv); }
+void voc_free(void* vv) {
+    voc_bind((Voc*)vv);
+    voc_destroy((Voc*)vv);
+}
 
 void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
     int ndev = 0;
@@ -1387,6 +1399,7 @@ void* voc_load(const char* weights, int chunk_tokens, int max_batch) {
     // (any chunk length decodes; the chunk walk of voc_synthesize needs chunk > 32 and says so itself)
     if (const char* ex = getenv("Q3_VOC_EXACT")) g_voc_split = atoi(ex) ? 0 : 1;
     Voc* v = new Voc();
+    hipGetDevice(&v->device);
     v->chunk = chunk_tokens > 0 ? chunk_tokens : 64;
     v->max_batch = max_batch > 0 ? max_batch : 1;
     bool ok = true;
@@ -2002,6 +2015,7 @@ static int voc_run(Voc* v, int B, float** out_dev, int n_ops = -1, int* outC = n
 
 int voc_decode(void* vv, const int64_t* codes, int B, float* out) {
     Voc* v = (Voc*)vv;
+    voc_bind(v);
     if (!v || !codes || !out || B <= 0 || B > v->max_batch) return -1;
     Q3_HIP(hipMemcpyAsync(v->d_codes, codes, sizeof(int64_t) * 16 * (size_t)v->chunk * B, hipMemcpyHostToDevice, v->s), -1);
     Q3_HIP(hipEventRecord(v->e0, v->s), -1);
@@ -2033,6 +2047,7 @@ int voc_decode(void* vv, const int64_t* codes, int B, float* out) {
 // test hook: per-op GPU milliseconds of one decode of B chunks (codes already uploaded by a previous voc_decode)
 int voc_debug_profile(void* vv, int B, float* op_ms, int max_ops) {
     Voc* v = (Voc*)vv;
+    voc_bind(v);
     if (!v || B <= 0 || B > v->max_batch || (int)v->ops.size() > max_ops) return -1;
     float* res = nullptr;
     if (voc_run(v, B, &res, -1, nullptr, nullptr, op_ms)) return -1;
@@ -2042,6 +2057,7 @@ int voc_debug_profile(void* vv, int B, float* op_ms, int max_ops) {
 // test hook: run only the first n_ops ops, return the activation [B][C][L]
 int voc_debug_run(void* vv, const int64_t* codes, int B, int n_ops, float* out, int* C, int* L) {
     Voc* v = (Voc*)vv;
+    voc_bind(v);
     if (!v || B <= 0 || B > v->max_batch) return -1;
     Q3_HIP(hipMemcpyAsync(v->d_codes, codes, sizeof(int64_t) * 16 * (size_t)v->chunk * B, hipMemcpyHostToDevice, v->s), -1);
     float* res = nullptr;
@@ -2075,6 +2091,7 @@ int voc_synthesize_max_samples(void* vv, int n) {
 // VocoderServer.synthesize (vocoder_server.py:73-121), bug-compatible chunk walk, float output.
 int voc_synthesize_f32(void* vv, const int64_t* codes, int n, float* out, int32_t* n_samples) {
     Voc* v = (Voc*)vv;
+    voc_bind(v);
     if (!v || !codes || !out || !n_samples || n <= 0) return -1;
     const int CH = v->chunk, SPT = v->upsample;
     // numpy slicing, as the reference writes it: `audio[:len * SAMPLES_PER_TOKEN]` of what the model returned --
@@ -2183,6 +2200,7 @@ size_t plan_walk(const Voc* v, int u, int n, long long base, std::vector<WalkChu
 }
 
 int synth_batch(Voc* v, const int64_t* codes, const int32_t* n_tokens, int U, int64_t* offsets, bool want16, void* out, int64_t cap) {
+    voc_bind(v);
     if (!v || !codes || !n_tokens || !offsets || !out || U <= 0) return -1;
     const int CH = v->chunk;
     std::vector<WalkChunk> walk;
